@@ -291,9 +291,10 @@ def frame(scene: dict, view: dict, hzb: HzbTexture, depth: np.ndarray | None, *,
     d.threads = int(threads)
 
     if record_capacity is None:
-        lod_groups = (md["lods"]["numMeshlets"].astype(np.uint64) + 31) // 32
+        lods = md[md.dtype.names[1]]
+        lod_groups = (lods[lods.dtype.names[1]].astype(np.uint64) + 31) // 32
         per_mesh = lod_groups.max(axis=1) if len(md) else np.zeros(0, np.uint64)
-        record_capacity = int(per_mesh[inst["meshDataIdx"]].sum()) + 1 if len(inst) else 1
+        record_capacity = int(per_mesh[inst[inst.dtype.names[2]]].sum()) + 1 if len(inst) else 1
         record_capacity = min(record_capacity, max(int(maxGroups), 1))
     if list_capacity is None:
         list_capacity = record_capacity * 32

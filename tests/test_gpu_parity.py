@@ -1,0 +1,269 @@
+"""Parity of the HIP path (through the C ABI, include/trhip.h) against the CPU oracle.
+
+Bar: bit-exact (integer / index / fp16-texel outputs).  PARITY UNPINNED with respect to the
+reference itself (no reference fixtures exist): the oracle is the scalar restatement
+of the HLSL in oracle/tr_oracle.c.  Everything here needs a real MI355X.
+"""
+import numpy as np
+import pytest
+
+from toyrenderer_amd import interop as I
+from toyrenderer_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from toyrenderer_amd import rhi
+    d = rhi.Device(0)
+    yield d
+    d.destroy()
+
+
+def _oracle_hzb(oracle, view, depth):
+    hw, hh = view.hzb_dims
+    h = oracle.HzbTexture(hw, hh)
+    if depth is not None:
+        h.build_from_depth(depth)
+    return h
+
+
+def _upload_hzb(driver, hzb):
+    driver.hzb.upload_chain(hzb.texels, hzb.offsets)
+
+
+def _compare_frame(got, ref, slots=(0, 1, 2, 3)):
+    for s in slots:
+        if not ref.passRan[s]:
+            assert got[s] is None, f"slot {s} ran on the GPU but not in the oracle"
+            continue
+        g = got[s]
+        assert g is not None, f"slot {s} did not run on the GPU"
+        assert np.array_equal(g["dispatchArgs"], ref.dispatchArgs[s]), (s, g["dispatchArgs"], ref.dispatchArgs[s])
+        assert g["validRecords"] == int(ref.validRecords[s]), s
+        assert np.array_equal(g["records"].view(np.uint32), ref.records[s].view(np.uint32)), f"slot {s}: records differ"
+        assert np.array_equal(g["visMask"], ref.visMask[s]), f"slot {s}: visibility masks differ"
+        assert np.array_equal(g["drawArgs"], ref.drawArgs[s]), (s, g["drawArgs"], ref.drawArgs[s])
+        assert np.array_equal(g["visibleList"], ref.visibleList[s]), f"slot {s}: visible lists differ"
+
+
+def _run_case(dev, oracle, spec, view, *, flags=7, forced=-1, max_groups=65535, depth_prev=None, depth_cur=None,
+              freeze=False, frames=1):
+    from toyrenderer_amd.frame import FrameDriver, GpuScene
+    scene = synth.make_scene(spec)
+    gs = GpuScene(dev, scene.instances, scene.meshData, scene.meshlets, scene.opaqueIds, scene.alphaMaskIds)
+    drv = FrameDriver(dev, gs, view, record_capacity=max_groups, culling_flags=flags, force_mesh_lod=forced,
+                      freeze_culling_camera=freeze)
+    hzb = _oracle_hzb(oracle, view, depth_prev)
+    if depth_prev is not None:
+        _upload_hzb(drv, hzb)
+    if depth_cur is not None:
+        drv.depth.upload_mip(0, depth_cur)
+    try:
+        for _ in range(frames):
+            drv.record()
+            drv.run()
+            got = drv.results()
+            ref = oracle.frame(scene.as_oracle(), view.as_dict(), hzb, depth_cur, cullingFlags=flags, forceMeshLOD=forced,
+                               freeze=freeze, maxGroups=max_groups, record_capacity=max_groups)
+            _compare_frame(got, ref)
+            if flags & 2:
+                assert got["lateCount"] == int(ref.lateCount[1] if scene.alphaMaskIds.size else ref.lateCount[0])
+            # the HZB the frame leaves behind (consumed by the next frame's early pass)
+            if flags & 2 and depth_cur is not None and not freeze:
+                assert np.array_equal(drv.hzb.download_chain(), hzb.texels), "HZB chain differs"
+        return got, ref
+    finally:
+        drv.release()
+        gs.release()
+
+
+SMALL = synth.SceneSpec(num_meshes=24, num_instances=300, meshlets_lod0=70, jitter_meshlets=True, max_lods=5,
+                        alpha_mask_fraction=0.15, seed=1234)
+
+
+@pytest.mark.parametrize("flags", range(8))
+def test_frame_all_flag_combinations(dev, oracle, flags):
+    view = synth.make_view(eye=(0.5, 0.2, 1.0), yaw=0.03, prev_eye=(0.0, 0.0, 0.0), prev_yaw=0.0, render=(640, 360))
+    d_prev = synth.gen_depth(view, num_occluders=60, seed=11, scale=3.0)
+    d_cur = synth.gen_depth(view, num_occluders=40, seed=12, scale=3.0)
+    got, ref = _run_case(dev, oracle, SMALL, view, flags=flags, depth_prev=d_prev, depth_cur=d_cur)
+    if flags == 7:
+        assert ref.lateCount[0] > 0 and ref.dispatchArgs[1][0] > 0, "case must exercise the late pass"
+        assert 0 < ref.drawArgs[0][0] < ref.meshletsTested[0]
+
+
+@pytest.mark.parametrize("forced", [0, 1, 3, 7, 200])
+def test_forced_lod(dev, oracle, forced):
+    view = synth.make_view(render=(640, 360))
+    d = synth.gen_depth(view, num_occluders=30, seed=3, scale=3.0)
+    _run_case(dev, oracle, SMALL, view, flags=7, forced=forced, depth_prev=d, depth_cur=d)
+
+
+def test_c1_sponza_scale_frustum_cone(dev, oracle):
+    """BASELINE configs[1]: ~50 k meshlets... (C1 = 400 instances), phase-1 frustum + cone only."""
+    view = synth.make_view()
+    _run_case(dev, oracle, synth.config_spec("C1"), view, flags=5)
+
+
+def test_c0_tiny(dev, oracle):
+    view = synth.make_view(eye=(0, 0, 0), render=(1280, 720))
+    d = synth.gen_depth(view, 5, seed=9, scale=3.0)
+    _run_case(dev, oracle, synth.config_spec("C0"), view, flags=7, depth_prev=d, depth_cur=d)
+
+
+def test_group_cap_overflow_q2(dev, oracle):
+    """Q2: the counter keeps counting, everything from the first dropped instance on is undefined."""
+    view = synth.make_view(render=(640, 360))
+    spec = synth.SceneSpec(num_meshes=10, num_instances=500, meshlets_lod0=90, jitter_meshlets=True, max_lods=1, seed=77)
+    got, ref = _run_case(dev, oracle, spec, view, flags=1, max_groups=257)
+    assert ref.dispatchArgs[0][0] > 257 and ref.validRecords[0] < 257
+
+
+def test_late_list_q1_odd_sizes(dev, oracle):
+    """Q1: only ceil(count/64)*32 late entries are re-tested.  Everything occluded in phase 1
+    (HZB = near everywhere), nothing occluded in phase 2 (depth = far)."""
+    view = synth.make_view(render=(640, 360))
+    hw, hh = view.hzb_dims
+    near_everywhere = np.ones((view.renderH, view.renderW), np.float32)
+    far = np.zeros((view.renderH, view.renderW), np.float32)
+    for n in (1, 31, 33, 64, 65, 97, 200):
+        spec = synth.SceneSpec(num_meshes=4, num_instances=n, meshlets_lod0=40, max_lods=1, seed=n, z_near=20.0, z_far=60.0,
+                               box_x=4.0, box_y=3.0)
+        got, ref = _run_case(dev, oracle, spec, view, flags=2, depth_prev=near_everywhere, depth_cur=far)
+        assert ref.lateCount[0] == n, "all instances must be deferred to the late pass"
+        expect = min(n, ((n + 63) // 64) * 32)
+        assert len(np.unique(ref.records[1]["instanceConstIdx"])) == expect
+
+
+def test_two_frames_hzb_feedback(dev, oracle):
+    view = synth.make_view(eye=(0.2, 0.0, 0.5), yaw=0.01, render=(1280, 720))
+    d = synth.gen_depth(view, num_occluders=80, seed=21, scale=3.0)
+    _run_case(dev, oracle, SMALL, view, flags=7, depth_prev=None, depth_cur=d, frames=2)
+
+
+def test_freeze_culling_camera_skips_hzb(dev, oracle):
+    view = synth.make_view(render=(640, 360))
+    d_prev = synth.gen_depth(view, num_occluders=60, seed=11, scale=3.0)
+    d_cur = synth.gen_depth(view, num_occluders=40, seed=12, scale=3.0)
+    _run_case(dev, oracle, SMALL, view, flags=7, depth_prev=d_prev, depth_cur=d_cur, freeze=True)
+
+
+def test_empty_lists(dev, oracle):
+    view = synth.make_view(render=(640, 360))
+    spec = synth.SceneSpec(num_meshes=3, num_instances=40, meshlets_lod0=10, max_lods=2, alpha_mask_fraction=0.0, seed=5)
+    got, ref = _run_case(dev, oracle, spec, view, flags=5)
+    assert got[2] is None and got[1] is None
+
+
+def test_cone_unorm_all_byte_values(dev, oracle):
+    """x/255 for every byte value (cull_math.hip.h u8Unorm) through the cone test."""
+    from toyrenderer_amd.frame import FrameDriver, GpuScene
+    view = synth.make_view(render=(640, 360))
+    spec = synth.SceneSpec(num_meshes=1, num_instances=64, meshlets_lod0=256, max_lods=1, seed=42, z_near=8, z_far=30, box_x=3, box_y=2)
+    scene = synth.make_scene(spec)
+    b = np.arange(256, dtype=np.uint32)
+    rng = np.random.default_rng(1)
+    scene.meshlets["m_ConeAxisAndCutoff"] = b | (rng.permutation(256).astype(np.uint32) << 8) | (rng.permutation(256).astype(np.uint32) << 16) | (b[::-1] << 24)
+    gs = GpuScene(dev, scene.instances, scene.meshData, scene.meshlets, scene.opaqueIds, scene.alphaMaskIds)
+    drv = FrameDriver(dev, gs, view, record_capacity=4096, culling_flags=4)
+    try:
+        drv.record(); drv.run()
+        got = drv.results()
+        hzb = _oracle_hzb(oracle, view, None)
+        ref = oracle.frame(scene.as_oracle(), view.as_dict(), hzb, None, cullingFlags=4, maxGroups=4096, record_capacity=4096)
+        _compare_frame(got, ref, slots=(0,))
+        assert 0 < ref.drawArgs[0][0] < ref.meshletsTested[0]
+    finally:
+        drv.release(); gs.release()
+
+
+@pytest.mark.parametrize("render", [(100, 40), (640, 360), (1920, 1080), (3840, 2160), (2560, 1440)])
+def test_hzb_build(dev, oracle, render):
+    """minmaxdownsample + SPD replacement vs orc_hzb_build, incl. a non-tiled (<64) and non-square chain."""
+    from toyrenderer_amd.frame import FrameDriver, GpuScene
+    view = synth.make_view(render=render)
+    rng = np.random.default_rng(render[0])
+    depth = rng.random((render[1], render[0]), np.float32) ** 6
+    depth[rng.random(depth.shape) < 0.2] = 0
+    spec = synth.SceneSpec(num_meshes=1, num_instances=1, meshlets_lod0=1)
+    scene = synth.make_scene(spec)
+    gs = GpuScene(dev, scene.instances, scene.meshData, scene.meshlets, scene.opaqueIds, scene.alphaMaskIds)
+    drv = FrameDriver(dev, gs, view, record_capacity=64)
+    try:
+        drv.depth.upload_mip(0, depth)
+        cl = drv.cl
+        cl.open(); drv._generate_hzb(cl); cl.close()
+        dev.execute(cl)
+        dev.wait_idle()
+        ref = _oracle_hzb(oracle, view, depth)
+        assert np.array_equal(drv.hzb.download_chain(), ref.texels)
+    finally:
+        drv.release(); gs.release()
+
+
+def test_update_instance_consts(dev, oracle):
+    from toyrenderer_amd import rhi
+    rng = np.random.default_rng(8)
+    n_nodes, n_inst = 500, 2000
+    nodes = np.zeros(n_nodes, I.NodeLocalTransform)
+    nodes["m_Position"] = rng.standard_normal((n_nodes, 3)).astype(np.float32) * 5
+    q = rng.standard_normal((n_nodes, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    nodes["m_Rotation"] = q.astype(np.float32)
+    nodes["m_Scale"] = rng.uniform(0.5, 2.0, (n_nodes, 3)).astype(np.float32)
+    parent = np.full(n_nodes, 0xFFFFFFFF, np.uint32)
+    for i in range(1, n_nodes):
+        if rng.random() < 0.8:
+            parent[i] = rng.integers(0, i)          # parents precede children: chains up to ~10 deep
+    nodes["m_ParentNodeIdx"] = parent
+    prim = rng.integers(0, n_nodes, n_inst).astype(np.uint32)
+    inst = np.zeros(n_inst, I.BasePassInstanceConstants)
+    inst["m_WorldMatrix"] = rng.standard_normal((n_inst, 4, 4)).astype(np.float32)
+    b_nodes = dev.buffer_from(nodes, "nodes", uav=False); b_prim = dev.buffer_from(prim, "prim", uav=False)
+    b_inst = dev.buffer_from(inst, "inst")
+    cl = dev.create_command_list()
+    k = np.array([n_inst], np.uint32)
+    cl.open()
+    for _ in range(2):
+        cl.dispatch("updateinstanceconsts_CS_UpdateInstanceConstsAndBuildTLAS",
+                    [rhi.PUSH(0), rhi.SRV(0, b_nodes), rhi.SRV(1, b_prim), rhi.UAV(0, b_inst)], ((n_inst + 31) // 32, 1, 1), push=k)
+    cl.close()
+    dev.execute(cl)
+    got = b_inst.download(I.BasePassInstanceConstants)
+    ref = inst.copy()
+    oracle.update_instance_consts(nodes, prim, ref); oracle.update_instance_consts(nodes, prim, ref)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    cl.release(); b_nodes.release(); b_prim.release(); b_inst.release()
+
+
+def test_errors_are_reported_not_fatal(dev):
+    from toyrenderer_amd import rhi
+    cl = dev.create_command_list()
+    cl.open()
+    with pytest.raises(rhi.TrhipError, match="unknown shader"):
+        cl.dispatch("no_such_shader", [], (1, 1, 1))
+    with pytest.raises(rhi.TrhipError, match="constant buffer b0"):
+        cl.dispatch("gpuculling_CS_GPUCulling LATE_CULL=0", [], (1, 1, 1))
+    cl.close()
+    cl.release()
+
+
+def test_deterministic_across_runs(dev, oracle):
+    from toyrenderer_amd.frame import FrameDriver, GpuScene
+    view = synth.make_view(render=(1280, 720))
+    scene = synth.make_scene(synth.config_spec("C1"))
+    d = synth.gen_depth(view, 50, seed=2, scale=3.0)
+    gs = GpuScene(dev, scene.instances, scene.meshData, scene.meshlets, scene.opaqueIds, scene.alphaMaskIds)
+    drv = FrameDriver(dev, gs, view, record_capacity=65535, culling_flags=7)
+    drv.depth.upload_mip(0, d)
+    try:
+        outs = []
+        for _ in range(3):
+            drv.record(); drv.run()
+            r = drv.results()
+            outs.append((r[0]["visibleList"].copy(), r[1]["visibleList"].copy() if r[1] else None, r[0]["records"].copy()))
+        # frame 0 sees the cleared HZB, frames 1 and 2 the same rebuilt HZB -> identical bytes
+        assert np.array_equal(outs[1][0], outs[2][0]) and np.array_equal(outs[1][2], outs[2][2])
+    finally:
+        drv.release(); gs.release()

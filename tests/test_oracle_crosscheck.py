@@ -41,7 +41,7 @@ def small_world(oracle):
                            alpha_mask_fraction=0.15, seed=1234)
     scene = synth.make_scene(spec)
     view = synth.make_view(eye=(0.5, 0.2, 1.0), yaw=0.03, prev_eye=(0.0, 0.0, 0.0), prev_yaw=0.0, render=(640, 360))
-    depth = synth.gen_depth(view, num_occluders=60)
+    depth = synth.gen_depth(view, num_occluders=60, scale=3.0)
     hw, hh = view.hzb_dims
     hzb = oracle.HzbTexture(hw, hh)
     hzb.build_from_depth(depth)

@@ -1,0 +1,178 @@
+// cull_math.hip.h -- device-side arithmetic of the visibility tests (gfx950).
+//
+// Follows the reference HLSL (source/shaders/culling.hlsli, toyrenderer_common.hlsli,
+// basepass.hlsl:90-108, gpuculling.hlsl:39-57) under the arithmetic convention of DESIGN.md
+// "Arithmetic": IEEE binary32, no implicit contraction (-ffp-contract=off on this translation
+// unit), matrix and dot products as explicit v_fma_f32 chains, correctly rounded '/' and sqrt
+// (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt), floor(log2) by exponent extraction,
+// fp16 HZB texels.  Results are compared bit for bit with the CPU oracle by the -m gpu tests.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "ShaderInterop.h"
+
+namespace cm
+{
+
+struct F3 { float x, y, z; };
+
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ float min_(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ float max_(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ float sqrt_(float a) { return __builtin_sqrtf(a); }
+__device__ __forceinline__ float clamp_(float x, float lo, float hi) { return min_(max_(x, lo), hi); }
+
+__device__ __forceinline__ float dot3(F3 a, F3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
+
+__device__ __forceinline__ F3 cross3(F3 a, F3 b)
+{
+    return { fma_(a.y, b.z, -(a.z * b.y)), fma_(a.z, b.x, -(a.x * b.z)), fma_(a.x, b.y, -(a.y * b.x)) };
+}
+
+// Rows 0..3 (xyz) of a row-major 4x4: everything mul(float4(p,1), M).xyz needs.
+struct M43 { F3 r0, r1, r2, r3; };
+
+// mul(float4(p,1), M).xyz
+__device__ __forceinline__ F3 mulPoint(F3 p, const M43& m)
+{
+    return { fma_(p.z, m.r2.x, fma_(p.y, m.r1.x, p.x * m.r0.x)) + m.r3.x,
+             fma_(p.z, m.r2.y, fma_(p.y, m.r1.y, p.x * m.r0.y)) + m.r3.y,
+             fma_(p.z, m.r2.z, fma_(p.y, m.r1.z, p.x * m.r0.z)) + m.r3.z };
+}
+
+// mul(float3, float3x3(r0,r1,r2))
+__device__ __forceinline__ F3 mulVec(F3 v, F3 r0, F3 r1, F3 r2)
+{
+    return { fma_(v.z, r2.x, fma_(v.y, r1.x, v.x * r0.x)),
+             fma_(v.z, r2.y, fma_(v.y, r1.y, v.x * r0.y)),
+             fma_(v.z, r2.z, fma_(v.y, r1.z, v.x * r0.z)) };
+}
+
+// gpuculling.hlsl:118-119 / basepass.hlsl:68-69: view transform, then z *= -1
+__device__ __forceinline__ F3 toView(F3 p, const M43& v)
+{
+    F3 o = mulPoint(p, v);
+    o.z = -o.z;
+    return o;
+}
+
+// toyrenderer_common.hlsli:134-140
+__device__ __forceinline__ float maxScale(F3 r0, F3 r1, F3 r2)
+{
+    return sqrt_(max_(max_(dot3(r0, r0), dot3(r1, r1)), dot3(r2, r2)));
+}
+
+// culling.hlsli:6-21 (Q7); returns true = visible
+__device__ __forceinline__ bool frustumVisible(F3 c, float r, float fx, float fy, float fz, float fw)
+{
+    bool a = fma_(c.z, fy, __builtin_fabsf(c.x) * fx) < r;
+    bool b = fma_(c.z, fw, __builtin_fabsf(c.y) * fz) < r;
+    return a & b;
+}
+
+// HZB (R16_FLOAT mip chain) as the kernels see it.
+struct Hzb
+{
+    const _Float16* base;   // mip 0
+    uint32_t width, height, mips;
+    uint32_t mipOffset[16]; // in texels, relative to base
+};
+
+// floor(log2(max(w,h))) clamped by SampleLevel to [0,mips-1]; culling.hlsli:75 (Q6)
+__device__ __forceinline__ int hzbLevel(float width, float height, uint32_t mips)
+{
+    float m = max_(width, height);
+    if (!(m >= 1.0f)) return 0;
+    int e = (int)((__float_as_uint(m) >> 23) & 0xFFu) - 127;
+    int last = (int)mips - 1;
+    return e > last ? last : e;
+}
+
+// SampleLevel with the linear-clamp MIN-reduction sampler (culling.hlsli:78,
+// CommonResources.cpp:276-287,298): min over the bilinear footprint texels of non-zero weight.
+__device__ __forceinline__ float sampleHzbMin(const Hzb& h, float u, float v, int mip)
+{
+    uint32_t mw = (h.width >> mip) ? (h.width >> mip) : 1u;
+    uint32_t mh = (h.height >> mip) ? (h.height >> mip) : 1u;
+    const _Float16* t = h.base + h.mipOffset[mip];
+    float fx = fma_(u, (float)mw, -0.5f);
+    float fy = fma_(v, (float)mh, -0.5f);
+    float flx = __builtin_floorf(fx), fly = __builtin_floorf(fy);
+    int x0 = (int)flx, y0 = (int)fly;
+    bool wx1 = (fx - flx) > 0.0f, wy1 = (fy - fly) > 0.0f;
+    int xm = (int)mw - 1, ym = (int)mh - 1;
+    int x1 = min(max(x0 + 1, 0), xm), y1 = min(max(y0 + 1, 0), ym);
+    x0 = min(max(x0, 0), xm);
+    y0 = min(max(y0, 0), ym);
+    // a texel of zero weight is replaced by the (always taken) texel 00: same minimum
+    x1 = wx1 ? x1 : x0;
+    y1 = wy1 ? y1 : y0;
+    float d00 = (float)t[(uint32_t)y0 * mw + (uint32_t)x0];
+    float d01 = (float)t[(uint32_t)y0 * mw + (uint32_t)x1];
+    float d10 = (float)t[(uint32_t)y1 * mw + (uint32_t)x0];
+    float d11 = (float)t[(uint32_t)y1 * mw + (uint32_t)x1];
+    return min_(min_(min_(d00, d01), d10), d11);
+}
+
+// culling.hlsli:36-82; returns true = visible
+__device__ __forceinline__ bool occlusionVisible(F3 c, float r, float nearPlane, float P00, float P11, const Hzb& h)
+{
+    if ((c.z - nearPlane) < r) return true;                          // :48-49
+    float crx = c.x * r, cry = c.y * r, crz = c.z * r;               // :53
+    float czr2 = fma_(c.z, c.z, -(r * r));                           // :54
+    float vx = sqrt_(fma_(c.x, c.x, czr2));                          // :56
+    float minx = fma_(vx, c.x, -crz) / fma_(vx, c.z, crx);           // :57
+    float maxx = fma_(vx, c.x, crz) / fma_(vx, c.z, -crx);           // :58
+    float vy = sqrt_(fma_(c.y, c.y, czr2));                          // :60
+    float miny = fma_(vy, c.y, -crz) / fma_(vy, c.z, cry);           // :61
+    float maxy = fma_(vy, c.y, crz) / fma_(vy, c.z, -cry);           // :62
+    float ax = clamp_(minx * P00, -1.0f, 1.0f);                      // :64-67
+    float ay = clamp_(miny * P11, -1.0f, 1.0f);
+    float az = clamp_(maxx * P00, -1.0f, 1.0f);
+    float aw = clamp_(maxy * P11, -1.0f, 1.0f);
+    ax = fma_(ax, 0.5f, 0.5f);                                       // :70-71 ClipXYToUV
+    ay = fma_(ay, -0.5f, 0.5f);
+    az = fma_(az, 0.5f, 0.5f);
+    aw = fma_(aw, -0.5f, 0.5f);
+    float width = (az - ax) * (float)h.width;                        // :73
+    float height = (aw - ay) * (float)h.height;                      // :74
+    int level = hzbLevel(width, height, h.mips);                     // :75
+    float depth = sampleHzbMin(h, (ax + az) * 0.5f, (ay + aw) * 0.5f, level); // :78
+    float depthSphere = nearPlane / (c.z - r);                       // :79
+    return depthSphere >= depth;                                     // :81
+}
+
+// x / 255.0f for x in [0,255], correctly rounded (== IEEE division; verified exhaustively by
+// tests/test_gpu_primitives.py): one Newton correction of x * RN(1/255).
+__device__ __forceinline__ float u8Unorm(uint32_t x)
+{
+    const float r = 0x1.010102p-8f;          // RN(1/255)
+    float xf = (float)x;
+    float q = xf * r;
+    float rem = fma_(-q, 255.0f, xf);
+    return fma_(rem, r, q);
+}
+
+// basepass.hlsl:92-108; adj0..2 = MakeAdjugateMatrix(world) rows (toyrenderer_common.hlsli:124-132).
+// Returns true = back-facing (ConeCull, culling.hlsli:84-87).
+__device__ __forceinline__ bool coneBackfacing(uint32_t packed, F3 cv, float r, F3 adj0, F3 adj1, F3 adj2, const M43& view)
+{
+    float q0 = u8Unorm(packed & 0xFFu), q1 = u8Unorm((packed >> 8) & 0xFFu);
+    float q2 = u8Unorm((packed >> 16) & 0xFFu), cutoff = u8Unorm(packed >> 24);
+    F3 a = { fma_(q0, 2.0f, -1.0f), fma_(q1, 2.0f, -1.0f), fma_(q2, 2.0f, -1.0f) };
+    F3 t = mulVec(a, adj0, adj1, adj2);
+    float len = sqrt_(dot3(t, t));
+    t = { t.x / len, t.y / len, t.z / len };                         // normalize = v / length
+    F3 axis = mulVec(t, view.r0, view.r1, view.r2);
+    axis.z = -axis.z;
+    return dot3(cv, axis) >= fma_(cutoff, sqrt_(dot3(cv, cv)), r);
+}
+
+__device__ __forceinline__ M43 loadM43(const interop::Matrix& m)
+{
+    return { { m.m[0][0], m.m[0][1], m.m[0][2] }, { m.m[1][0], m.m[1][1], m.m[1][2] },
+             { m.m[2][0], m.m[2][1], m.m[2][2] }, { m.m[3][0], m.m[3][1], m.m[3][2] } };
+}
+
+} // namespace cm

@@ -1,0 +1,354 @@
+// k_basepass_as.hip -- compute replacement of the amplification shader AS_Main
+// ("basepass_AS_Main LATE_CULL={0,1}", alias "basepass_AS_Main_cull") for gfx950.
+//
+// Reference: source/shaders/basepass.hlsl:40-122, launched by dispatchMeshIndirect from
+// BasePassRenderer::RenderInstances (source/BasePassRenderers.cpp:406-503).  One reference group
+// = 32 lanes = 32 consecutive meshlets of one (instance, LOD) record; it ends in
+// DispatchMesh(numVisible, payload{indices in lane order}).  Here the per-group payload becomes
+//   visMask[g]       32-bit lane-visibility ballot of group g            (4 B / 32 meshlets)
+//   visibleList[k]   (g << 5) | lane, groups ascending, lanes ascending   (4 B / visible meshlet)
+//   drawArgs         {numVisibleTotal, 1, 1}
+// i.e. WavePrefixCountBits order inside a group (basepass.hlsl:116) and ascending group order
+// across groups (the canonical order of SURVEY.md section 7).  LATE_CULL is unused by the
+// reference's AS (Q5), so both permutations are the same kernel.
+//
+// This is the hot kernel of the path: HBM-bound streaming of MeshletData (32 B per meshlet
+// tested, algorithmic).  Structure for CDNA4:
+//   * a workgroup (256 threads = 4 wave64) owns a chunk of kChunk consecutive records;
+//   * prologue: one thread per record resolves record -> instance -> MeshData LOD entry (the
+//     three dependent loads of basepass.hlsl:54-58) ONCE per record, computes the per-record
+//     invariants (max scale, adjugate) and parks them in LDS;
+//   * main loop: a wave64 runs two records per step (lanes 0-31 / 32-63); per-record data comes
+//     from LDS as broadcast reads, so the only HBM stream is one coalesced 16-B (+4-B) load per
+//     lane; the next step's loads are issued before the current step's ALU work;
+//   * the 64-bit ballot is the two groups' visibility masks; masks are written once per chunk,
+//     together with the chunk's popcount (consumed by the scan/expand kernels below).
+#include "cull_math.hip.h"
+#include "trhip_internal.h"
+
+using namespace interop;
+
+namespace
+{
+
+constexpr uint32_t kBlock = 256;
+constexpr uint32_t kChunk = 128;                 // records per workgroup iteration
+constexpr uint32_t kRecordsPerStep = kBlock / 32;
+constexpr uint32_t kStepsPerChunk = kChunk / kRecordsPerStep;
+
+struct RecordInfo                                 // per-record invariants parked in LDS (96 B)
+{
+    float w[12];                                  // world matrix rows 0..3, xyz
+    float adj[9];                                 // MakeAdjugateMatrix rows
+    float maxScale;
+    uint32_t meshletBase;                         // m_MeshletDataBufferIdx + m_MeshletGroupOffset
+    uint32_t count;                               // lanes with meshletIdx < m_NumMeshlets (0..32)
+};
+
+struct MeshletCullArgs
+{
+    BasePassConstants k;
+    const BasePassInstanceConstants* instances;
+    const MeshData* meshData;
+    const MeshletData* meshlets;
+    const MeshletAmplificationData* records;
+    cm::Hzb hzb;
+    const uint32_t* dispatchArgs;                 // {X,1,1[,validRecords]} read on the device
+    uint32_t argsWords;
+    uint32_t recordCapacity;
+    uint64_t numMeshlets;                         // size of the meshlet buffer (bounds check)
+    uint32_t* visMask;
+    uint32_t* visibleList; uint32_t listCapacity;
+    uint32_t* drawArgs;
+    // scratch
+    uint32_t* chunkSum;                           // per chunk: visible meshlets -> exclusive prefix after scan
+    uint32_t maxChunks;
+};
+
+__device__ __forceinline__ uint32_t groupCount(const MeshletCullArgs& a)
+{
+    uint32_t G = a.dispatchArgs[0];
+    if (a.argsWords > 3 && a.dispatchArgs[3] < G) G = a.dispatchArgs[3];   // Q2: only the defined prefix
+    return G < a.recordCapacity ? G : a.recordCapacity;
+}
+
+struct MeshletRegs { float4 sphere; uint32_t cone; };
+
+__device__ __forceinline__ MeshletRegs loadMeshlet(const MeshletData* meshlets, uint32_t idx, bool active)
+{
+    MeshletRegs m;
+    m.sphere = make_float4(0.f, 0.f, 0.f, 0.f);
+    m.cone = 0;
+    if (active) {
+        const MeshletData* p = meshlets + idx;
+        m.sphere = *reinterpret_cast<const float4*>(p);                              // basepass.hlsl:65
+        m.cone = p->m_ConeAxisAndCutoff;
+    }
+    return m;
+}
+
+template <bool FRUSTUM, bool OCCLUSION, bool CONE>
+__global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
+{
+    __shared__ RecordInfo s_rec[kChunk];
+    __shared__ uint32_t s_mask[kChunk];
+    __shared__ uint32_t s_wavePop[kBlock / 64];
+
+    const uint32_t G = groupCount(a);
+    const uint32_t numChunks = (G + kChunk - 1) / kChunk;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t half = lane >> 5, sub = lane & 31u;
+    const cm::M43 V = cm::loadM43(a.k.m_WorldToView);
+
+    for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
+        const uint32_t g0 = chunk * kChunk;
+        __syncthreads();                                                             // previous chunk's LDS reads done
+        // ---- prologue: resolve the chunk's records (basepass.hlsl:52-58) --------------------
+        if (tid < kChunk) {
+            RecordInfo ri;
+            ri.count = 0; ri.meshletBase = 0; ri.maxScale = 0.f;
+            const uint32_t g = g0 + tid;
+            if (g < G) {
+                const MeshletAmplificationData rec = a.records[g];
+                const BasePassInstanceConstants& inst = a.instances[rec.m_InstanceConstIdx];
+                const float4 w0 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[0]);
+                const float4 w1 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[1]);
+                const float4 w2 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[2]);
+                const float4 w3 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[3]);
+                const uint32_t lodIdx = rec.m_MeshLOD < kMaxNumMeshLODs ? rec.m_MeshLOD : kMaxNumMeshLODs - 1u;
+                const MeshLODData lod = a.meshData[inst.m_MeshDataIdx].m_MeshLODDatas[lodIdx];
+                const cm::F3 r0 = { w0.x, w0.y, w0.z }, r1 = { w1.x, w1.y, w1.z }, r2 = { w2.x, w2.y, w2.z };
+                ri.w[0] = w0.x; ri.w[1] = w0.y; ri.w[2] = w0.z;
+                ri.w[3] = w1.x; ri.w[4] = w1.y; ri.w[5] = w1.z;
+                ri.w[6] = w2.x; ri.w[7] = w2.y; ri.w[8] = w2.z;
+                ri.w[9] = w3.x; ri.w[10] = w3.y; ri.w[11] = w3.z;
+                ri.maxScale = cm::maxScale(r0, r1, r2);                              // toyrenderer_common.hlsli:134-140
+                const cm::F3 a0 = cm::cross3(r1, r2), a1 = cm::cross3(r2, r0), a2 = cm::cross3(r0, r1); // :124-132
+                ri.adj[0] = a0.x; ri.adj[1] = a0.y; ri.adj[2] = a0.z;
+                ri.adj[3] = a1.x; ri.adj[4] = a1.y; ri.adj[5] = a1.z;
+                ri.adj[6] = a2.x; ri.adj[7] = a2.y; ri.adj[8] = a2.z;
+                // lanes with meshletIdx = groupOffset + lane < numMeshlets (basepass.hlsl:62-63)
+                const uint32_t off = rec.m_MeshletGroupOffset;
+                uint32_t cnt = lod.m_NumMeshlets > off ? lod.m_NumMeshlets - off : 0u;
+                cnt = cnt < 32u ? cnt : 32u;
+                const uint64_t base = (uint64_t)lod.m_MeshletDataBufferIdx + off;
+                if (base + cnt > a.numMeshlets) cnt = 0;                             // never read outside the meshlet buffer
+                ri.count = cnt;
+                ri.meshletBase = (uint32_t)base;
+            }
+            s_rec[tid] = ri;
+        }
+        __syncthreads();
+
+        // ---- main loop: two records per wave per step ----------------------------------------
+        uint32_t wavePop = 0;
+        uint32_t r = wave * 2 + half;                                                // record within the chunk
+        MeshletRegs cur = loadMeshlet(a.meshlets, s_rec[r].meshletBase + sub, sub < s_rec[r].count);
+#pragma unroll 1
+        for (uint32_t step = 0; step < kStepsPerChunk; ++step) {
+            const uint32_t rn = r + kRecordsPerStep;
+            MeshletRegs nxt;
+            if (step + 1 < kStepsPerChunk)
+                nxt = loadMeshlet(a.meshlets, s_rec[rn].meshletBase + sub, sub < s_rec[rn].count);
+
+            const RecordInfo& ri = s_rec[r];
+            bool vis = sub < ri.count;
+            if (vis) {
+                const cm::M43 W = { { ri.w[0], ri.w[1], ri.w[2] }, { ri.w[3], ri.w[4], ri.w[5] },
+                                    { ri.w[6], ri.w[7], ri.w[8] }, { ri.w[9], ri.w[10], ri.w[11] } };
+                const cm::F3 cw = cm::mulPoint({ cur.sphere.x, cur.sphere.y, cur.sphere.z }, W);   // :67
+                const cm::F3 cv = cm::toView(cw, V);                                               // :68-69
+                const float rad = cur.sphere.w * ri.maxScale;                                      // :71
+                if (FRUSTUM)
+                    vis = cm::frustumVisible(cv, rad, a.k.m_Frustum.x, a.k.m_Frustum.y, a.k.m_Frustum.z, a.k.m_Frustum.w); // :73
+                if (OCCLUSION && vis)
+                    vis = cm::occlusionVisible(cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb);    // :75-88 (Q4)
+                if (CONE && vis)
+                    vis = !cm::coneBackfacing(cur.cone, cv, rad, { ri.adj[0], ri.adj[1], ri.adj[2] },
+                                              { ri.adj[3], ri.adj[4], ri.adj[5] }, { ri.adj[6], ri.adj[7], ri.adj[8] }, V); // :90-108
+            }
+            const unsigned long long ballot = __ballot(vis);                        // :116,120 WavePrefix/ActiveCountBits
+            if (sub == 0) s_mask[r] = (uint32_t)(ballot >> (half * 32));
+            wavePop += (uint32_t)__popcll(ballot);
+            cur = nxt;
+            r = rn;
+        }
+        if (lane == 0) s_wavePop[wave] = wavePop;
+        __syncthreads();
+        if (tid < kChunk && g0 + tid < G) a.visMask[g0 + tid] = s_mask[tid];
+        if (tid == 0) a.chunkSum[chunk] = s_wavePop[0] + s_wavePop[1] + s_wavePop[2] + s_wavePop[3];
+    }
+}
+
+// One block: exclusive scan of the chunk sums -> list offsets; total -> drawArgs.
+__global__ __launch_bounds__(1024) void visScanKernel(MeshletCullArgs a)
+{
+    __shared__ uint32_t s_v[1024];
+    __shared__ uint32_t s_carry;
+    const uint32_t G = groupCount(a);
+    const uint32_t numChunks = (G + kChunk - 1) / kChunk;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < numChunks; base += 1024) {
+        const uint32_t i = base + tid;
+        const uint32_t v = i < numChunks ? a.chunkSum[i] : 0u;
+        s_v[tid] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) {
+            uint32_t p = tid >= d ? s_v[tid - d] : 0u;
+            __syncthreads();
+            s_v[tid] += p;
+            __syncthreads();
+        }
+        if (i < numChunks) a.chunkSum[i] = s_carry + s_v[tid] - v;
+        __syncthreads();
+        if (tid == 1023) s_carry += s_v[1023];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        a.drawArgs[0] = s_carry;       // replaces DispatchMesh(numVisible,1,1) summed over groups (basepass.hlsl:120-121)
+        a.drawArgs[1] = 1;
+        a.drawArgs[2] = 1;
+    }
+}
+
+// Ordered compaction: one thread per (group, lane) slot; a visible slot's position is the chunk
+// offset + popcounts of the earlier groups of its chunk + WavePrefixCountBits inside its group.
+__global__ __launch_bounds__(kBlock) void visExpandKernel(MeshletCullArgs a)
+{
+    __shared__ uint32_t s_mask[kChunk];
+    __shared__ uint32_t s_off[kChunk];
+    const uint32_t G = groupCount(a);
+    const uint32_t numChunks = (G + kChunk - 1) / kChunk;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
+        const uint32_t g0 = chunk * kChunk;
+        __syncthreads();
+        if (tid < kChunk) s_mask[tid] = g0 + tid < G ? a.visMask[g0 + tid] : 0u;
+        __syncthreads();
+        if (tid < 64) {                                   // wave 0: exclusive scan of 128 popcounts, 2 per lane
+            const uint32_t p0 = (uint32_t)__popc(s_mask[2 * lane]), p1 = (uint32_t)__popc(s_mask[2 * lane + 1]);
+            uint32_t inc = p0 + p1;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t n = __shfl_up(inc, d);
+                if (lane >= (uint32_t)d) inc += n;
+            }
+            const uint32_t exc = inc - (p0 + p1);
+            s_off[2 * lane] = exc;
+            s_off[2 * lane + 1] = exc + p0;
+        }
+        __syncthreads();
+        const uint32_t chunkBase = a.chunkSum[chunk];
+        for (uint32_t step = 0; step < kStepsPerChunk; ++step) {
+            const uint32_t r = step * kRecordsPerStep + (tid >> 5);
+            const uint32_t sub = tid & 31u;
+            const uint32_t m = s_mask[r];
+            if (m & (1u << sub)) {
+                const uint32_t pos = chunkBase + s_off[r] + (uint32_t)__popc(m & ((1u << sub) - 1u));
+                if (pos < a.listCapacity) a.visibleList[pos] = ((g0 + r) << 5) | sub;
+            }
+        }
+    }
+}
+
+template <bool F, bool O, bool C>
+void launchCull(const MeshletCullArgs& a, uint32_t grid, hipStream_t s)
+{
+    hipLaunchKernelGGL((meshletCullKernel<F, O, C>), dim3(grid), dim3(kBlock), 0, s, a);
+}
+
+int recordASMain(trhip::DispatchCtx& ctx)
+{
+    // Binding set of BasePassRenderers.cpp:463-479 (t0 instances, t2 mesh data, t4 meshlets,
+    // t7 amplification records, t8 HZB) + this build's outputs u0 visMask, u1 visibleList, u2 drawArgs.
+    const BasePassConstants* k = (const BasePassConstants*)ctx.constants(0, sizeof(BasePassConstants));
+    TRHIP_REQUIRE(k, "%s: constant buffer b0 (BasePassConstants, 256 bytes) missing", ctx.shaderName);
+    trhip_buffer_t* instances = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 0);
+    trhip_buffer_t* meshData = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 2);
+    trhip_buffer_t* meshlets = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 4);
+    trhip_buffer_t* records = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 7);
+    trhip_texture_t* hzb = ctx.texture(TRHIP_BIND_TEXTURE_SRV, 8);
+    trhip_buffer_t* visMask = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 0);
+    trhip_buffer_t* visList = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 1);
+    trhip_buffer_t* drawArgs = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 2);
+    TRHIP_REQUIRE(instances && meshData && meshlets && records, "%s: needs SRVs t0, t2, t4, t7 (BasePassRenderers.cpp:463-479)", ctx.shaderName);
+    TRHIP_REQUIRE(visMask && visList && drawArgs, "%s: needs UAVs u0 (visMask), u1 (visibleList), u2 (drawArgs)", ctx.shaderName);
+    TRHIP_REQUIRE(ctx.indirect, "%s: launched by dispatchMeshIndirect (BasePassRenderers.cpp:497-502): use dispatch_indirect", ctx.shaderName);
+    TRHIP_REQUIRE(instances->byteSize % sizeof(BasePassInstanceConstants) == 0, "%s: instance buffer size is not a multiple of 144", ctx.shaderName);
+    TRHIP_REQUIRE(meshlets->byteSize % sizeof(MeshletData) == 0, "%s: meshlet buffer size is not a multiple of 32", ctx.shaderName);
+    TRHIP_REQUIRE(drawArgs->byteSize >= 12, "%s: drawArgs buffer smaller than 12 bytes", ctx.shaderName);
+
+    MeshletCullArgs a;
+    memset(&a, 0, sizeof a);
+    a.k = *k;
+    const bool occlusion = (k->m_CullingFlags & kCullingFlagOcclusionCullingEnable) != 0;
+    int rc = TRHIP_OK;
+    {
+        memset(&a.hzb, 0, sizeof a.hzb);
+        if (occlusion) {
+            TRHIP_REQUIRE(hzb, "%s: occlusion culling enabled but no HZB texture bound at t8", ctx.shaderName);
+            TRHIP_REQUIRE(hzb->format == TRHIP_FORMAT_R16_FLOAT, "%s: HZB is not R16_FLOAT", ctx.shaderName);
+            TRHIP_REQUIRE(hzb->width == k->m_HZBDimensions.x && hzb->height == k->m_HZBDimensions.y,
+                          "%s: m_HZBDimensions %ux%u does not match the HZB texture %ux%u", ctx.shaderName,
+                          k->m_HZBDimensions.x, k->m_HZBDimensions.y, hzb->width, hzb->height);
+            a.hzb.base = (const _Float16*)hzb->ptr;
+            a.hzb.width = hzb->width; a.hzb.height = hzb->height; a.hzb.mips = hzb->mips;
+            for (uint32_t m = 0; m < hzb->mips; ++m) a.hzb.mipOffset[m] = (uint32_t)(hzb->mipOffset[m] / 2);
+        }
+    }
+    if (rc != TRHIP_OK) return rc;
+    a.instances = (const BasePassInstanceConstants*)instances->ptr;
+    a.meshData = (const MeshData*)meshData->ptr;
+    a.meshlets = (const MeshletData*)meshlets->ptr;
+    a.records = (const MeshletAmplificationData*)records->ptr;
+    a.dispatchArgs = (const uint32_t*)((const char*)ctx.argsBuffer->ptr + ctx.argsOffset);
+    a.argsWords = (ctx.argsBuffer->byteSize - ctx.argsOffset) >= 16 ? 4u : 3u;
+    const uint64_t cap = records->byteSize / sizeof(MeshletAmplificationData);
+    a.recordCapacity = cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;
+    TRHIP_REQUIRE(a.recordCapacity <= (1u << 27), "%s: more than 2^27 records cannot be encoded as (g<<5)|lane", ctx.shaderName);
+    TRHIP_REQUIRE(visMask->byteSize / 4 >= a.recordCapacity, "%s: visMask holds %llu groups, records buffer %u", ctx.shaderName,
+                  (unsigned long long)(visMask->byteSize / 4), a.recordCapacity);
+    a.numMeshlets = meshlets->byteSize / sizeof(MeshletData);
+    a.visMask = (uint32_t*)visMask->ptr;
+    a.visibleList = (uint32_t*)visList->ptr;
+    const uint64_t lcap = visList->byteSize / 4;
+    a.listCapacity = lcap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)lcap;
+    a.drawArgs = (uint32_t*)drawArgs->ptr;
+    a.maxChunks = (a.recordCapacity + kChunk - 1) / kChunk;
+    a.chunkSum = (uint32_t*)ctx.scratch((size_t)a.maxChunks * 4);
+    TRHIP_REQUIRE(a.chunkSum, "%s: scratch allocation failed", ctx.shaderName);
+
+    // Persistent grid: the group count lives on the device (indirect), so launch enough
+    // workgroups to fill the chip and let them stride over the chunks.
+    uint32_t grid = ctx.computeUnits() * 8u;
+    if (grid > a.maxChunks) grid = a.maxChunks;
+    if (grid == 0) grid = 1;
+    const uint32_t flags = k->m_CullingFlags & 7u;
+    ctx.emit("cull", [a, grid, flags](hipStream_t s) {
+        switch (flags) {
+        case 0: launchCull<false, false, false>(a, grid, s); break;
+        case 1: launchCull<true, false, false>(a, grid, s); break;
+        case 2: launchCull<false, true, false>(a, grid, s); break;
+        case 3: launchCull<true, true, false>(a, grid, s); break;
+        case 4: launchCull<false, false, true>(a, grid, s); break;
+        case 5: launchCull<true, false, true>(a, grid, s); break;
+        case 6: launchCull<false, true, true>(a, grid, s); break;
+        default: launchCull<true, true, true>(a, grid, s); break;
+        }
+        return trhip::launchStatus("meshletCullKernel"); });
+    ctx.emit("scan", [a](hipStream_t s) {
+        hipLaunchKernelGGL(visScanKernel, dim3(1), dim3(1024), 0, s, a);
+        return trhip::launchStatus("visScanKernel"); });
+    ctx.emit("expand", [a, grid](hipStream_t s) {
+        hipLaunchKernelGGL(visExpandKernel, dim3(grid), dim3(kBlock), 0, s, a);
+        return trhip::launchStatus("visExpandKernel"); });
+    return TRHIP_OK;
+}
+
+trhip::ShaderRegistrar r0("basepass_AS_Main LATE_CULL=0", recordASMain, 0);
+trhip::ShaderRegistrar r1("basepass_AS_Main LATE_CULL=1", recordASMain, 1);
+trhip::ShaderRegistrar r2("basepass_AS_Main_cull", recordASMain, 0);
+
+} // namespace

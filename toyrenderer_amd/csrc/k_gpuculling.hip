@@ -1,0 +1,358 @@
+// k_gpuculling.hip -- "gpuculling_CS_GPUCulling LATE_CULL={0,1}" and
+// "gpuculling_CS_BuildLateCullIndirectArgs" for gfx950.
+//
+// Reference: source/shaders/gpuculling.hlsl:35-195, dispatched by
+// BasePassRenderer::GPUCulling (source/BasePassRenderers.cpp:298-404).
+//
+// The reference appends amplification records and late-list entries with global atomics, so its
+// output ORDER is whatever order the atomics resolve in.  This build defines the canonical order
+// = ascending dispatch-thread id (SURVEY.md section 7 "Determinism vs. atomics") and produces it
+// with prefix sums instead of atomics, in three launches on one stream:
+//   A  classify   one thread per list entry: frustum + HZB test + LOD select; block-level
+//                 exclusive scan of (groups to emit, late flags) -> per-block sums
+//   B  scan       one block: exclusive scan of the per-block sums, final counters
+//   C  emit       one thread per list entry: writes its records / late-list entry at its offset
+// HBM traffic: 4 B id + 68 B of the 144-B instance record + MeshData per entry (A), 8 B of
+// scratch per entry (A write, C read), 12 B per record (C).  Bound: HBM; the pass is <5 % of a
+// frame on the 100 M-meshlet config (DESIGN.md "Kernels").
+#include "cull_math.hip.h"
+#include "trhip_internal.h"
+
+using namespace interop;
+
+namespace
+{
+
+constexpr uint32_t kBlock = 256;
+constexpr uint32_t kWordSubmit = 1u << 30;
+constexpr uint32_t kWordLate = 1u << 31;
+constexpr uint32_t kGroupMask = (1u << 27) - 1u;
+
+struct InstanceCullArgs
+{
+    GPUCullingPassConstants k;
+    const BasePassInstanceConstants* instances;
+    const uint32_t* ids;            // primitive ids (early) / late-list ids (late)
+    const MeshData* meshData;
+    cm::Hzb hzb;
+    MeshletAmplificationData* records;
+    uint32_t* dispatchArgs;         // {X,Y,Z[,validRecords]}
+    uint32_t* lateCount;
+    uint32_t* lateIds;
+    const uint32_t* indirectArgs;   // late: {ceil(count/64),1,1} (Q1)
+    uint32_t directThreads;         // early: gx * 32
+    uint32_t maxGroups;             // capacity of `records` (65535 in the reference, Q2)
+    uint32_t argsWords;             // 3 or 4
+    // scratch
+    uint32_t* word;                 // per entry: groups | lod<<27 | submit<<30 | late<<31
+    uint32_t* localOff;             // per entry: exclusive offset inside its block
+    uint32_t* blockGroups;          // per block: sum of groups      -> exclusive prefix after B
+    uint64_t* blockLateSubmit;      // per block: late | submits<<32 -> exclusive prefix after B
+    uint32_t* bases;                // [0] X before the pass, [1] late count before the pass
+    uint32_t numBlocks;
+};
+
+template <int LATE>
+__device__ __forceinline__ uint32_t threadCount(const InstanceCullArgs& a)
+{
+    if (LATE) {
+        // gpuculling.hlsl:94-103 with the dispatch size of :182-195 (Q1: ceil(count/64) groups of 32)
+        uint32_t count = *a.lateCount;
+        uint64_t launched = (uint64_t)a.indirectArgs[0] * kNumThreadsPerWave;
+        uint32_t n = launched < count ? (uint32_t)launched : count;
+        return n < a.k.m_NbInstances ? n : a.k.m_NbInstances;
+    }
+    return a.directThreads < a.k.m_NbInstances ? a.directThreads : a.k.m_NbInstances;
+}
+
+__device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t n = __shfl_up(v, d);
+        if (lane >= (uint32_t)d) v += n;
+    }
+    return v;
+}
+
+// gpuculling.hlsl:105-178 up to the ordered side effects.
+template <int LATE>
+__device__ __forceinline__ uint32_t classify(const InstanceCullArgs& a, uint32_t id)
+{
+    const GPUCullingPassConstants& k = a.k;
+    const bool doFrustum = (k.m_CullingFlags & kCullingFlagFrustumCullingEnable) != 0;
+    const bool doOcclusion = (k.m_CullingFlags & kCullingFlagOcclusionCullingEnable) != 0;
+
+    const BasePassInstanceConstants& inst = a.instances[id];                       // :114
+    const float4 w0 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[0]);
+    const float4 w1 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[1]);
+    const float4 w2 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[2]);
+    const float4 w3 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[3]);
+    const cm::M43 W = { { w0.x, w0.y, w0.z }, { w1.x, w1.y, w1.z }, { w2.x, w2.y, w2.z }, { w3.x, w3.y, w3.z } };
+    const MeshData& mesh = a.meshData[inst.m_MeshDataIdx];
+    const float4 sph = *reinterpret_cast<const float4*>(&mesh.m_BoundingSphere);
+
+    const float ms = cm::maxScale(W.r0, W.r1, W.r2);
+    const cm::F3 wc = cm::mulPoint({ sph.x, sph.y, sph.z }, W);                    // :116 TransformBoundingSphereToWorld
+    const float r = sph.w * ms;
+    cm::F3 cv = cm::toView(wc, cm::loadM43(k.m_WorldToView));                      // :118-119
+
+    if (!LATE && doFrustum &&                                                      // :124-134
+        !cm::frustumVisible(cv, r, k.m_Frustum.x, k.m_Frustum.y, k.m_Frustum.z, k.m_Frustum.w))
+        return 0;
+
+    if (doOcclusion) {
+        if (!LATE) cv = cm::toView(wc, cm::loadM43(k.m_PrevWorldToView));          // :143-146 (Q3)
+        if (!cm::occlusionVisible(cv, r, k.m_NearPlane, k.m_P00, k.m_P11, a.hzb))  // :148-158
+            return LATE ? 0 : kWordLate;                                           // :162-178
+    }
+
+    // SubmitInstance :35-62
+    const uint32_t numLODs = mesh.m_NumLODs;
+    uint32_t lod = 0;
+    if (k.m_ForcedMeshLOD != kInvalidMeshLOD) {
+        const uint32_t last = numLODs - 1u;
+        lod = k.m_ForcedMeshLOD < last ? k.m_ForcedMeshLOD : last;
+    } else {
+        const float distance = cm::max_(cm::sqrt_(cm::dot3(cv, cv)) - r, 0.0f);
+        const float threshold = distance * k.m_MeshLODTarget / ms;
+        const uint32_t n = numLODs < kMaxNumMeshLODs ? numLODs : kMaxNumMeshLODs;
+        for (uint32_t i = 1; i < n; ++i)
+            if (mesh.m_MeshLODDatas[i].m_Error < threshold) lod = i;
+    }
+    lod = lod < kMaxNumMeshLODs ? lod : kMaxNumMeshLODs - 1u;                       // never index past the struct
+    const uint32_t numMeshlets = mesh.m_MeshLODDatas[lod].m_NumMeshlets;
+    const uint32_t groups = (numMeshlets + kNumThreadsPerWave - 1u) / kNumThreadsPerWave; // DivideAndRoundUp
+    return kWordSubmit | (lod << 27) | (groups & kGroupMask);
+}
+
+template <int LATE>
+__global__ __launch_bounds__(kBlock) void instanceClassifyKernel(InstanceCullArgs a)
+{
+    __shared__ uint32_t s_waveG[kBlock / 64];
+    __shared__ uint32_t s_waveL[kBlock / 64];
+    __shared__ uint32_t s_waveS[kBlock / 64];
+
+    const uint32_t n = threadCount<LATE>(a);
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+
+    uint32_t word = 0;
+    if (t < n) word = classify<LATE>(a, a.ids[t]);
+
+    const uint32_t g = (word & kWordSubmit) ? (word & kGroupMask) : 0u;
+    const uint32_t late = word >> 31;
+    const uint32_t submit = (word >> 30) & 1u;
+
+    const uint32_t incG = waveInclusiveScan(g, lane);
+    const uint32_t incL = waveInclusiveScan(late, lane);
+    const uint32_t cntS = (uint32_t)__popcll(__ballot(submit != 0));
+    if (lane == 63) { s_waveG[wave] = incG; s_waveL[wave] = incL; s_waveS[wave] = cntS; }
+    __syncthreads();
+    uint32_t baseG = 0, baseL = 0, totG = 0, totL = 0, totS = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kBlock / 64; ++w) {
+        if (w < wave) { baseG += s_waveG[w]; baseL += s_waveL[w]; }
+        totG += s_waveG[w]; totL += s_waveL[w]; totS += s_waveS[w];
+    }
+    if (t < n) {
+        a.word[t] = word;
+        a.localOff[t] = late ? (baseL + incL - late) : (baseG + incG - g);
+    }
+    if (threadIdx.x == 0) {
+        a.blockGroups[blockIdx.x] = totG;
+        a.blockLateSubmit[blockIdx.x] = (uint64_t)totL | ((uint64_t)totS << 32);
+    }
+}
+
+// One block: exclusive scan over the per-block sums; final counters.
+template <int LATE>
+__global__ __launch_bounds__(1024) void instanceScanKernel(InstanceCullArgs a)
+{
+    __shared__ uint32_t s_g[1024];
+    __shared__ uint64_t s_ls[1024];
+    __shared__ uint32_t s_carryG;
+    __shared__ uint64_t s_carryLS;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) { s_carryG = 0; s_carryLS = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < a.numBlocks; base += 1024) {
+        const uint32_t i = base + tid;
+        const uint32_t g = i < a.numBlocks ? a.blockGroups[i] : 0u;
+        const uint64_t ls = i < a.numBlocks ? a.blockLateSubmit[i] : 0ull;
+        s_g[tid] = g; s_ls[tid] = ls;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) {            // Hillis-Steele, 10 steps
+            uint32_t pg = tid >= d ? s_g[tid - d] : 0u;
+            uint64_t pl = tid >= d ? s_ls[tid - d] : 0ull;
+            __syncthreads();
+            s_g[tid] += pg; s_ls[tid] += pl;
+            __syncthreads();
+        }
+        if (i < a.numBlocks) {
+            a.blockGroups[i] = s_carryG + s_g[tid] - g;
+            a.blockLateSubmit[i] = s_carryLS + s_ls[tid] - ls;
+        }
+        __syncthreads();
+        if (tid == 1023) { s_carryG += s_g[1023]; s_carryLS += s_ls[1023]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const uint32_t baseX = a.dispatchArgs[0];
+        const uint32_t baseLate = LATE ? 0u : *a.lateCount;
+        a.bases[0] = baseX;
+        a.bases[1] = baseLate;
+        const uint32_t X = baseX + s_carryG;                  // gpuculling.hlsl:65 (counter still counts drops, Q2)
+        a.dispatchArgs[0] = X;
+        if ((uint32_t)(s_carryLS >> 32) != 0) {               // :66-67, only when something was submitted
+            a.dispatchArgs[1] = 1;
+            a.dispatchArgs[2] = 1;
+        }
+        if (a.argsWords > 3) a.dispatchArgs[3] = X;           // valid records; the first dropped instance lowers it in C
+        if (!LATE) *a.lateCount = baseLate + (uint32_t)s_carryLS;   // :165
+    }
+}
+
+template <int LATE>
+__global__ __launch_bounds__(kBlock) void instanceEmitKernel(InstanceCullArgs a)
+{
+    const uint32_t n = threadCount<LATE>(a);
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t word = a.word[t];
+    if (word & kWordLate) {                                                         // :162-167
+        const uint32_t idx = a.bases[1] + (uint32_t)a.blockLateSubmit[blockIdx.x] + a.localOff[t];
+        a.lateIds[idx] = a.ids[t];
+        return;
+    }
+    if (!(word & kWordSubmit)) return;
+    const uint32_t groups = word & kGroupMask;
+    const uint32_t lod = (word >> 27) & 7u;
+    const uint32_t off = a.bases[0] + a.blockGroups[blockIdx.x] + a.localOff[t];    // :65
+    if (off + groups >= a.maxGroups) {                                              // :69-74 (Q2)
+        if (groups != 0 && off < a.maxGroups && a.argsWords > 3) a.dispatchArgs[3] = off;
+        return;
+    }
+    const uint32_t id = a.ids[t];
+    for (uint32_t i = 0; i < groups; ++i) {                                         // :76-84
+        MeshletAmplificationData rec = { id, lod, i * kNumThreadsPerWave };
+        a.records[off + i] = rec;
+    }
+}
+
+__global__ void buildLateCullIndirectArgsKernel(const uint32_t* count, uint32_t* args)
+{
+    args[0] = (count[0] + 63u) / 64u;                                               // gpuculling.hlsl:192 (Q1)
+    args[1] = 1;
+    args[2] = 1;
+}
+
+int fillHzb(const trhip::DispatchCtx& ctx, trhip_texture_t* tex, const Vector2U& dims, bool occlusion, cm::Hzb* out)
+{
+    memset(out, 0, sizeof *out);
+    if (!occlusion) return TRHIP_OK;
+    TRHIP_REQUIRE(tex, "%s: occlusion culling enabled but no HZB texture bound", ctx.shaderName);
+    TRHIP_REQUIRE(tex->format == TRHIP_FORMAT_R16_FLOAT, "%s: HZB '%s' is not R16_FLOAT", ctx.shaderName, tex->name.c_str());
+    TRHIP_REQUIRE(tex->width == dims.x && tex->height == dims.y,
+                  "%s: m_HZBDimensions %ux%u does not match HZB texture %ux%u", ctx.shaderName, dims.x, dims.y, tex->width, tex->height);
+    out->base = (const _Float16*)tex->ptr;
+    out->width = tex->width; out->height = tex->height; out->mips = tex->mips;
+    for (uint32_t k = 0; k < tex->mips; ++k) out->mipOffset[k] = (uint32_t)(tex->mipOffset[k] / 2);
+    return TRHIP_OK;
+}
+
+template <int LATE>
+int recordGPUCulling(trhip::DispatchCtx& ctx)
+{
+    // Binding set of BasePassRenderers.cpp:351-362.
+    const GPUCullingPassConstants* k = (const GPUCullingPassConstants*)ctx.constants(0, sizeof(GPUCullingPassConstants));
+    TRHIP_REQUIRE(k, "%s: constant buffer b0 (GPUCullingPassConstants, 180 bytes) missing", ctx.shaderName);
+    trhip_buffer_t* instances = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 0);
+    trhip_buffer_t* ids = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 1);
+    trhip_buffer_t* meshData = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 2);
+    trhip_texture_t* hzb = ctx.texture(TRHIP_BIND_TEXTURE_SRV, 3);
+    trhip_buffer_t* records = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 0);
+    trhip_buffer_t* args = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 1);
+    trhip_buffer_t* lateCount = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 2);
+    trhip_buffer_t* lateIds = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 3);
+    TRHIP_REQUIRE(instances && ids && meshData && records && args && lateCount && lateIds,
+                  "%s: needs SRVs t0..t2 and UAVs u0..u3 (BasePassRenderers.cpp:351-362)", ctx.shaderName);
+    const bool occlusion = (k->m_CullingFlags & kCullingFlagOcclusionCullingEnable) != 0;
+    TRHIP_REQUIRE(instances->byteSize % sizeof(BasePassInstanceConstants) == 0, "%s: instance buffer size is not a multiple of 144", ctx.shaderName);
+    TRHIP_REQUIRE(meshData->byteSize % sizeof(MeshData) == 0, "%s: mesh data buffer size is not a multiple of 156", ctx.shaderName);
+    TRHIP_REQUIRE(records->byteSize >= sizeof(MeshletAmplificationData), "%s: amplification buffer too small", ctx.shaderName);
+    TRHIP_REQUIRE(args->byteSize >= 12, "%s: dispatch-arguments buffer smaller than 12 bytes", ctx.shaderName);
+    if (LATE) {
+        TRHIP_REQUIRE(ctx.indirect, "%s: LATE_CULL=1 is dispatched indirectly (BasePassRenderers.cpp:399)", ctx.shaderName);
+        TRHIP_REQUIRE(occlusion, "%s: LATE_CULL=1 without occlusion culling", ctx.shaderName);
+        TRHIP_REQUIRE((uint64_t)k->m_NbInstances * 4 <= lateIds->byteSize, "%s: late id buffer smaller than m_NbInstances", ctx.shaderName);
+    } else {
+        TRHIP_REQUIRE(!ctx.indirect, "%s: LATE_CULL=0 is dispatched directly", ctx.shaderName);
+        TRHIP_REQUIRE((uint64_t)k->m_NbInstances * 4 <= ids->byteSize, "%s: m_NbInstances %u exceeds the id buffer", ctx.shaderName, k->m_NbInstances);
+        if (occlusion)
+            TRHIP_REQUIRE((uint64_t)k->m_NbInstances * 4 <= lateIds->byteSize, "%s: late id buffer smaller than m_NbInstances", ctx.shaderName);
+    }
+    TRHIP_REQUIRE(lateCount->byteSize >= 4, "%s: late counter buffer too small", ctx.shaderName);
+
+    InstanceCullArgs a;
+    memset(&a, 0, sizeof a);
+    a.k = *k;
+    int rc = fillHzb(ctx, hzb, k->m_HZBDimensions, occlusion, &a.hzb);
+    if (rc != TRHIP_OK) return rc;
+    a.instances = (const BasePassInstanceConstants*)instances->ptr;
+    a.ids = LATE ? (const uint32_t*)lateIds->ptr : (const uint32_t*)ids->ptr;
+    a.meshData = (const MeshData*)meshData->ptr;
+    a.records = (MeshletAmplificationData*)records->ptr;
+    a.dispatchArgs = (uint32_t*)args->ptr;
+    a.lateCount = (uint32_t*)lateCount->ptr;
+    a.lateIds = (uint32_t*)lateIds->ptr;
+    a.indirectArgs = LATE ? (const uint32_t*)((const char*)ctx.argsBuffer->ptr + ctx.argsOffset) : nullptr;
+    const uint64_t direct = (uint64_t)ctx.gx * kNumThreadsPerWave;
+    a.directThreads = direct > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)direct;
+    const uint64_t cap = records->byteSize / sizeof(MeshletAmplificationData);
+    a.maxGroups = cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;
+    a.argsWords = args->byteSize >= 16 ? 4u : 3u;
+
+    const uint32_t nMax = k->m_NbInstances;
+    if (nMax == 0) return TRHIP_OK;
+    a.numBlocks = (nMax + kBlock - 1) / kBlock;
+    a.word = (uint32_t*)ctx.scratch((size_t)nMax * 4);
+    a.localOff = (uint32_t*)ctx.scratch((size_t)nMax * 4);
+    a.blockGroups = (uint32_t*)ctx.scratch((size_t)a.numBlocks * 4);
+    a.blockLateSubmit = (uint64_t*)ctx.scratch((size_t)a.numBlocks * 8);
+    a.bases = (uint32_t*)ctx.scratch(16);
+    TRHIP_REQUIRE(a.word && a.localOff && a.blockGroups && a.blockLateSubmit && a.bases, "%s: scratch allocation failed", ctx.shaderName);
+
+    ctx.emit("classify", [a](hipStream_t s) {
+        hipLaunchKernelGGL(instanceClassifyKernel<LATE>, dim3(a.numBlocks), dim3(kBlock), 0, s, a);
+        return trhip::launchStatus("instanceClassifyKernel"); });
+    ctx.emit("scan", [a](hipStream_t s) {
+        hipLaunchKernelGGL(instanceScanKernel<LATE>, dim3(1), dim3(1024), 0, s, a);
+        return trhip::launchStatus("instanceScanKernel"); });
+    ctx.emit("emit", [a](hipStream_t s) {
+        hipLaunchKernelGGL(instanceEmitKernel<LATE>, dim3(a.numBlocks), dim3(kBlock), 0, s, a);
+        return trhip::launchStatus("instanceEmitKernel"); });
+    return TRHIP_OK;
+}
+
+int recordBuildLateArgs(trhip::DispatchCtx& ctx)
+{
+    // BasePassRenderers.cpp:379-388
+    trhip_buffer_t* count = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 0);
+    trhip_buffer_t* args = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 0);
+    TRHIP_REQUIRE(count && args, "%s: needs SRV t0 (late count) and UAV u0 (indirect args)", ctx.shaderName);
+    TRHIP_REQUIRE(count->byteSize >= 4 && args->byteSize >= 12, "%s: buffers too small", ctx.shaderName);
+    TRHIP_REQUIRE(!ctx.indirect && ctx.gx == 1 && ctx.gy == 1 && ctx.gz == 1, "%s: dispatched as 1x1x1", ctx.shaderName);
+    const uint32_t* c = (const uint32_t*)count->ptr;
+    uint32_t* a = (uint32_t*)args->ptr;
+    ctx.emit("main", [c, a](hipStream_t s) {
+        hipLaunchKernelGGL(buildLateCullIndirectArgsKernel, dim3(1), dim3(1), 0, s, c, a);
+        return trhip::launchStatus("buildLateCullIndirectArgsKernel"); });
+    return TRHIP_OK;
+}
+
+trhip::ShaderRegistrar r0("gpuculling_CS_GPUCulling LATE_CULL=0", recordGPUCulling<0>, 0);
+trhip::ShaderRegistrar r1("gpuculling_CS_GPUCulling LATE_CULL=1", recordGPUCulling<1>, 1);
+trhip::ShaderRegistrar r2("gpuculling_CS_BuildLateCullIndirectArgs", recordBuildLateArgs, 0);
+
+} // namespace

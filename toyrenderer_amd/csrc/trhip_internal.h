@@ -1,0 +1,177 @@
+// trhip_internal.h -- internals of the C-ABI back end (include/trhip.h).  Not part of the ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/trhip.h"
+#include "ShaderInterop.h"
+
+namespace trhip
+{
+
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+int hipfail(hipError_t e, const char* what);
+
+#define TRHIP_HIP(expr)                                                        \
+    do {                                                                       \
+        hipError_t _e = (expr);                                                \
+        if (_e != hipSuccess) return ::trhip::hipfail(_e, #expr);              \
+    } while (0)
+
+#define TRHIP_REQUIRE(cond, ...)                                               \
+    do {                                                                       \
+        if (!(cond)) return ::trhip::fail(TRHIP_ERR_INVALID, __VA_ARGS__);     \
+    } while (0)
+
+struct ProfilePending { std::string name; hipEvent_t e0, e1; };
+struct ProfileAccum { uint64_t launches = 0; double totalMs = 0; };
+
+} // namespace trhip
+
+struct trhip_device_t
+{
+    int index = 0;
+    hipStream_t stream = nullptr;
+    bool ownsStream = false;
+    uint32_t computeUnits = 0;
+    uint32_t waveSize = 0;
+    uint64_t totalMem = 0;
+
+    std::mutex mutex;
+    bool profiling = false;
+    std::vector<trhip::ProfilePending> pending;
+    std::vector<hipEvent_t> eventPool;
+    std::map<std::string, trhip::ProfileAccum> accum;
+    std::vector<std::string> accumOrder;
+
+    hipEvent_t acquireEvent();
+    int drainProfile();
+};
+
+struct trhip_heap_t
+{
+    trhip_device_t* dev = nullptr;
+    void* base = nullptr;
+    uint64_t bytes = 0;
+    std::atomic<int> rc{1};
+};
+
+struct trhip_buffer_t
+{
+    trhip_device_t* dev = nullptr;
+    uint64_t byteSize = 0;
+    uint32_t structStride = 0;
+    bool canHaveUAVs = false, isDrawIndirectArgs = false, isVirtual = false, isVolatileConstant = false;
+    std::string name;
+    void* ptr = nullptr;
+    bool owns = false;
+    trhip_heap_t* heap = nullptr;
+    std::vector<uint8_t> shadow; // current version of a volatile constant buffer (record time)
+    std::atomic<int> rc{1};
+};
+
+struct trhip_texture_t
+{
+    trhip_device_t* dev = nullptr;
+    uint32_t width = 0, height = 0, mips = 0, format = 0;
+    uint32_t texelBytes = 0;
+    bool isUAV = false, isVirtual = false;
+    std::string name;
+    uint64_t mipOffset[16] = {};
+    uint64_t totalBytes = 0;
+    void* ptr = nullptr;
+    bool owns = false;
+    trhip_heap_t* heap = nullptr;
+    std::atomic<int> rc{1};
+
+    uint32_t mipW(uint32_t k) const { return (width >> k) ? (width >> k) : 1u; }
+    uint32_t mipH(uint32_t k) const { return (height >> k) ? (height >> k) : 1u; }
+    void* mipPtr(uint32_t k) const { return (char*)ptr + mipOffset[k]; }
+};
+
+struct trhip_timer_t
+{
+    trhip_device_t* dev = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool began = false, ended = false;
+};
+
+namespace trhip
+{
+
+struct Op
+{
+    std::string name;                       // profile key ("" = not profiled)
+    std::function<int(hipStream_t)> fn;
+};
+
+} // namespace trhip
+
+struct trhip_cmdlist_t
+{
+    trhip_device_t* dev = nullptr;
+    bool open = false;
+    std::vector<trhip::Op> ops;
+    std::vector<trhip_buffer_t*> heldBuffers;
+    std::vector<trhip_texture_t*> heldTextures;
+    std::vector<std::string> markers;
+
+    struct ScratchBlock { void* ptr; size_t bytes; size_t used; };
+    std::vector<ScratchBlock> scratch;
+
+    void* scratchAlloc(size_t bytes);       // device memory valid until the list is re-opened/released
+    void resetRecording();
+    void hold(trhip_buffer_t* b);
+    void hold(trhip_texture_t* t);
+};
+
+namespace trhip
+{
+
+// What a shader's record function sees of one AddComputePass (Graphic.cpp:893-947).
+struct DispatchCtx
+{
+    trhip_cmdlist_t* cl;
+    const char* shaderName;
+    int variant;                            // e.g. LATE_CULL / FILTER value of the permutation
+    const trhip_binding* bindings; uint32_t numBindings;
+    const void* push; uint32_t pushBytes;
+    bool indirect; trhip_buffer_t* argsBuffer; uint32_t argsOffset;
+    uint32_t gx, gy, gz;
+
+    trhip_buffer_t* buffer(uint32_t type, uint32_t slot) const;
+    trhip_texture_t* texture(uint32_t type, uint32_t slot, uint32_t* baseMip = nullptr) const;
+    // Bytes of the constant buffer bound at b<slot> (volatile CB version at record time) or of
+    // the push constants; nullptr if absent / wrong size.
+    const void* constants(uint32_t slot, size_t bytes) const;
+    uint32_t computeUnits() const { return cl->dev->computeUnits; }
+    void* scratch(size_t bytes) const { return cl->scratchAlloc(bytes); }
+    void emit(const char* kernelName, std::function<int(hipStream_t)> fn) const;
+};
+
+using RecordFn = int (*)(DispatchCtx&);
+void registerShader(const char* name, RecordFn fn, int variant);
+
+struct ShaderRegistrar
+{
+    ShaderRegistrar(const char* name, RecordFn fn, int variant = 0) { registerShader(name, fn, variant); }
+};
+
+inline int launchStatus(const char* what)
+{
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TRHIP_OK : hipfail(e, what);
+}
+
+} // namespace trhip

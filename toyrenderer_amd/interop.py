@@ -87,3 +87,16 @@ def hzb_layout(w: int, h: int):
         offs.append(off)
         off += max(w >> k, 1) * max(h >> k, 1)
     return mips, offs, off
+
+
+def fmaf(a, b, c) -> np.float32:
+    """Exact scalar float32 fused multiply-add (std::fmaf): the product is exact in float64, the
+    float64 sum is rounded to odd, then rounded once to float32."""
+    a, b, c = np.float64(np.float32(a)), np.float64(np.float32(b)), np.float64(np.float32(c))
+    p = a * b
+    s = p + c
+    bb = s - p
+    err = (p - (s - bb)) + (c - bb)
+    if err != 0 and np.isfinite(s) and (np.float64(s).view(np.int64) & 1) == 0:
+        s = np.nextafter(s, np.inf if err > 0 else -np.inf)
+    return np.float32(s)

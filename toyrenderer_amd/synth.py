@@ -152,17 +152,18 @@ def gen_meshlets_for_meshes(spec: SceneSpec, md: np.ndarray, mesh_begin: int, me
     r = _rng(spec.seed, 2, mesh_begin // spec.chunk_meshes)
     ml = np.zeros(n, I.MeshletData)
     s = np.float32(spec.mesh_size)
-    ml["m_BoundingSphere"][:, :3] = (r.random((n, 3), np.float32) - np.float32(0.5)) * s
-    # radius log-uniform [0.01, 0.2] * mesh size
-    ml["m_BoundingSphere"][:, 3] = np.exp(r.uniform(math.log(0.01), math.log(0.2), n)).astype(np.float32) * s
-    axis = r.standard_normal((n, 3)).astype(np.float32)
-    axis /= np.maximum(np.linalg.norm(axis, axis=1, keepdims=True), np.float32(1e-20))
-    pa = ((axis + np.float32(1.0)) * np.float32(0.5) * np.float32(255.0)).astype(np.uint32)  # truncation, Visual.cpp:421-423
-    cutoff = (r.integers(0, 128, n).astype(np.uint32)) * 2                                     # Visual.cpp:424
-    ml["m_ConeAxisAndCutoff"] = pa[:, 0] | (pa[:, 1] << 8) | (pa[:, 2] << 16) | (cutoff << 24)
-    ml["m_MeshletVertexIDsBufferIdx"] = r.integers(0, 2 ** 31, n, dtype=np.uint32)
-    ml["m_MeshletIndexIDsBufferIdx"] = r.integers(0, 2 ** 31, n, dtype=np.uint32)
-    ml["m_VertexAndTriangleCount"] = r.integers(1, 65, n, dtype=np.uint32) | (r.integers(1, 97, n, dtype=np.uint32) << 8)
+    u = r.random((n, 4), np.float32)
+    bits = r.integers(0, 2 ** 32, (n, 4), dtype=np.uint32)
+    ml["m_BoundingSphere"][:, :3] = (u[:, :3] - np.float32(0.5)) * s
+    # radius ~log-uniform in [0.01, 0.32) * mesh size: 0.01 * (1 + u) * 2^k, k in 0..3 (exact scaling)
+    k = (bits[:, 3] >> 30).astype(np.int32)
+    ml["m_BoundingSphere"][:, 3] = np.ldexp((np.float32(1.0) + u[:, 3]) * (np.float32(0.01) * s), k).astype(np.float32)
+    # cone: axis bytes arbitrary (the shader normalises after the adjugate transform, basepass.hlsl:103),
+    # cutoff byte = 2 * cone_cutoff_s8: even, <= 254 (Visual.cpp:424)
+    ml["m_ConeAxisAndCutoff"] = bits[:, 0] & np.uint32(0xFEFFFFFF)
+    ml["m_MeshletVertexIDsBufferIdx"] = bits[:, 1] >> 1
+    ml["m_MeshletIndexIDsBufferIdx"] = bits[:, 2] >> 1
+    ml["m_VertexAndTriangleCount"] = ((bits[:, 3] & 63) + 1) | ((((bits[:, 3] >> 8) % 96) + 1) << 8)
     return ml
 
 
@@ -267,7 +268,7 @@ def config_spec(name: str) -> SceneSpec:
 
 
 # ----------------------------------------------------------------------------- synthetic depth
-def gen_depth(view: View, num_occluders: int = 200, seed: int = SEED_CAMERA) -> np.ndarray:
+def gen_depth(view: View, num_occluders: int = 200, seed: int = SEED_CAMERA, scale: float = 1.0) -> np.ndarray:
     """Analytic occluder field: screen-space boxes at constant view depth, reverse-Z
     (depth = near / z, far = 0, GraphicConstants kFarDepth).  float32 [renderH, renderW]."""
     W, H = view.renderW, view.renderH
@@ -275,7 +276,7 @@ def gen_depth(view: View, num_occluders: int = 200, seed: int = SEED_CAMERA) -> 
     depth = np.zeros((H, W), np.float32)
     for _ in range(num_occluders):
         z = float(r.uniform(15.0, 160.0))
-        w = int(r.uniform(0.01, 0.06) * W); h = int(r.uniform(0.02, 0.10) * H)
+        w = int(r.uniform(0.01, 0.06) * scale * W); h = int(r.uniform(0.02, 0.10) * scale * H)
         x0 = int(r.uniform(-0.05, 0.95) * W); y0 = int(r.uniform(-0.05, 0.95) * H)
         x1, y1 = min(W, x0 + w), min(H, y0 + h)
         x0, y0 = max(0, x0), max(0, y0)
