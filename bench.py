@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py -- Gmeshlets/s culled on the synthetic 100 M-meshlet scene (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A step = one full 2-phase visibility frame (BasePassRenderer::RenderBasePass,
+source/BasePassRenderers.cpp:544-588) over the scene shard(s) resident in HBM: early instance
+cull -> early meshlet cull -> HZB build -> late instance cull -> late meshlet cull -> HZB build
+[-> RCCL all-gather of the per-rank visible lists when N > 1].  value = meshlets tested per frame
+(all ranks) / max-over-ranks frame time.  Scaling is STRONG: the 100 M-meshlet scene is fixed and
+its instances are sharded over the ranks (north_star).
+
+One JSON line on rank 0 with the driver's contract plus "roofline" (dominant kernel: the meshlet
+cull, HIP-event timed on its own stream via the back end's per-shader profile) and "cpu_baseline"
+(the scalar C oracle timed on the host cores on a bounded sub-scene).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from toyrenderer_amd import interop as I  # noqa: E402
+from toyrenderer_amd import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+DOMINANT = "basepass_AS_Main LATE_CULL=0#cull"
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def shard_range(n: int, rank: int, world: int):
+    return (rank * n) // world, ((rank + 1) * n) // world
+
+
+def build_shard(spec: synth.SceneSpec, rank: int, world: int, dev, threads: int = 8):
+    """Upload this rank's shard: the full instance + mesh tables (replicated, ~230 MB), the id list of
+    the owned contiguous instance range, and ONLY the owned meshes' meshlets (co-sharded)."""
+    from toyrenderer_amd.frame import GpuScene
+    assert spec.unique, "the sharded bench uses the unique-meshlet configs (C3/C4)"
+    t0 = time.time()
+    md, total = synth.gen_mesh_table(spec)
+    i0, i1 = shard_range(spec.num_instances, rank, world)
+    cm = spec.chunk_meshes
+    # mesh i belongs to instance i (unique): the owned meshes are [i0, i1); generate the covering chunks
+    c0, c1 = (i0 // cm) * cm, min(((i1 + cm - 1) // cm) * cm, spec.num_meshes)
+    base = int(md["m_MeshLODDatas"]["m_MeshletDataBufferIdx"][i0, 0])
+    end = int(md["m_MeshLODDatas"]["m_MeshletDataBufferIdx"][i1 - 1, 0]) + int(md["m_MeshLODDatas"]["m_NumMeshlets"][i1 - 1].sum())
+    n_local = end - base
+    inst = synth.gen_instances(spec)
+    # rebase the owned meshes' meshlet indices into the local shard
+    md_local = md.copy()
+    lods = md_local["m_MeshLODDatas"]
+    owned = np.zeros(spec.num_meshes, bool); owned[i0:i1] = True
+    lods["m_MeshletDataBufferIdx"][owned] -= np.uint32(base)
+    lods["m_NumMeshlets"][~owned] = 0
+    ids = np.arange(i0, i1, dtype=np.uint32)
+    gs = GpuScene(dev, inst, md_local, None, ids, np.zeros(0, np.uint32), num_meshlets=max(n_local, 1))
+
+    def gen(b):
+        e = min(b + cm, spec.num_meshes)
+        return int(md["m_MeshLODDatas"]["m_MeshletDataBufferIdx"][b, 0]), synth.gen_meshlets_for_meshes(spec, md, b, e)
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        for off, chunk in ex.map(gen, range(c0, c1, cm)):
+            lo, hi = max(off, base), min(off + len(chunk), end)
+            if hi > lo:
+                gs.meshlets.upload(chunk[lo - off:hi - off], offset=(lo - base) * 32)
+    tested_upper = int(md["m_MeshLODDatas"]["m_NumMeshlets"][i0:i1, 0].sum())
+    log(f"[rank {rank}] shard: instances [{i0},{i1}) meshlets {n_local} ({n_local * 32 / 1e9:.2f} GB) in {time.time() - t0:.1f}s")
+    return gs, (i0, i1), n_local, total, tested_upper
+
+
+def cpu_baseline(spec: synth.SceneSpec, view, depth, sample_instances: int, threads: int):
+    """Time the scalar C oracle (oracle/tr_oracle.c) on the first `sample_instances` instances of the
+    same scene, same camera, same depth.  Checker code used as the reported CPU baseline only."""
+    from oracle import pyoracle
+    n = min(sample_instances, spec.num_instances)
+    n = (n // spec.chunk_meshes) * spec.chunk_meshes or min(spec.chunk_meshes, spec.num_instances)
+    sub = synth.SceneSpec(**{**spec.__dict__, "num_meshes": n, "num_instances": n})
+    full_md, _ = synth.gen_mesh_table(spec)
+    md = full_md[:n].copy()
+    total = int(md["m_MeshLODDatas"]["m_NumMeshlets"].sum())
+    ml = np.zeros(total, I.MeshletData)
+    for b in range(0, n, spec.chunk_meshes):
+        off = int(md["m_MeshLODDatas"]["m_MeshletDataBufferIdx"][b, 0])
+        chunk = synth.gen_meshlets_for_meshes(spec, full_md, b, min(b + spec.chunk_meshes, n))
+        ml[off:off + len(chunk)] = chunk
+    inst = synth.gen_instances(spec, 0, n)
+    scene = dict(instances=inst, meshData=md, meshlets=ml, opaqueIds=np.arange(n, dtype=np.uint32), alphaMaskIds=np.zeros(0, np.uint32))
+    hzb = pyoracle.HzbTexture(*view.hzb_dims)
+    hzb.build_from_depth(depth)
+    times, tested = [], 0
+    cap = n * ((spec.meshlets_lod0 + 31) // 32) + 1
+    for _ in range(3):
+        t = time.perf_counter()
+        ref = pyoracle.frame(scene, view.as_dict(), hzb, depth, cullingFlags=7, maxGroups=1 << 27, threads=threads, record_capacity=cap)
+        times.append(time.perf_counter() - t)
+        tested = int(ref.meshletsTested.sum())
+    dt = sorted(times)[1]
+    return dict(value=tested / dt / 1e9, unit="Gmeshlets/s", cores=threads, kind="port",
+                sample=f"first {n} instances ({total} meshlets in scene, {tested} tested/frame) of the same scene, full 2-phase frame incl. 2 HZB builds, median of 3, {dt * 1e3:.1f} ms/frame")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--cpu-sample-instances", type=int, default=65536)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from toyrenderer_amd import rhi
+    from toyrenderer_amd.frame import FrameDriver
+    from toyrenderer_amd.gather import VisibleListGather
+
+    stream = torch.cuda.current_stream().cuda_stream
+    dev = rhi.Device(local_rank, stream=stream)
+    spec = synth.config_spec(args.config)
+    view = synth.make_view(eye=(0.0, 0.0, 0.0), prev_eye=(0.05, 0.0, 0.1), prev_yaw=0.002)
+    depth = synth.gen_depth(view, 200)
+
+    gs, (i0, i1), n_local, n_total, tested_upper = build_shard(spec, rank, world, dev, threads=min(8, os.cpu_count() or 1))
+    groups_per_instance = (spec.meshlets_lod0 + 31) // 32
+    record_cap = (i1 - i0) * groups_per_instance + 1
+
+    gather = VisibleListGather(dev, dist, world, rank, record_cap, record_cap * 32) if world > 1 else None
+    drv = FrameDriver(dev, gs, view, record_capacity=record_cap, list_capacity=record_cap * 32, culling_flags=7,
+                      alloc=gather.alloc if gather else None)
+    drv.depth.upload_mip(0, depth)
+
+    def step():
+        drv.record()
+        drv.run()
+        if gather:
+            gather.run(drv)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):      # frame 0 sees the cleared HZB; steady state afterwards
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # work done per frame (device counters of the steady-state frame)
+    res = drv.results()
+    tested = 0
+    groups = 0
+    visible = 0
+    for s in (0, 1):
+        if res[s] is None:
+            continue
+        recs = res[s]["records"]
+        groups += len(recs)
+        visible += int(res[s]["drawArgs"][0])
+        nm = gs_num_meshlets(spec, recs)
+        tested += nm
+    counts = np.array([tested, groups, visible], np.int64)
+    if dist is not None:
+        t = torch.tensor(counts, device="cuda")
+        dist.all_reduce(t)
+        counts = t.cpu().numpy()
+    tested_all, groups_all, visible_all = (int(x) for x in counts)
+    ms_per_step = dt / args.steps * 1e3
+    value = tested_all / (dt / args.steps) / 1e9
+
+    # ---- roofline of the dominant kernel: HIP events on the kernel's own stream (back-end profile) ----
+    roofline = None
+    if not args.no_profile:
+        dev.profile_reset()
+        dev.profile_enable(True)
+        for _ in range(5):
+            drv.record()
+            drv.run()
+        dev.wait_idle()
+        prof = dev.profile()
+        dev.profile_enable(False)
+        n_launch, total_ms = prof[DOMINANT]
+        avg_ms = total_ms / n_launch
+        r0 = res[0]
+        t0_tested = gs_num_meshlets(spec, r0["records"])
+        inst_submitted = len(np.unique(r0["records"]["m_InstanceConstIdx"]))
+        # ALGORITHMIC bytes of one launch of the early meshlet-cull kernel (DESIGN.md "Kernels"):
+        # 32 B MeshletData per meshlet tested + 12 B record read + 4 B mask written per group
+        # + 68 B (world matrix + mesh index) per submitted instance
+        alg_bytes = 32 * t0_tested + 16 * len(r0["records"]) + 68 * inst_submitted
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        roofline = dict(bound="hbm", kernel=DOMINANT, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, avg_launch_ms=round(avg_ms, 4),
+                        algorithmic_bytes_per_launch=int(alg_bytes), meshlets_per_launch=int(t0_tested),
+                        per_kernel_ms={k: round(v[1] / v[0], 4) for k, v in prof.items()})
+
+    out = None
+    if rank == 0:
+        cpu = None
+        if not args.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline(spec, view, depth, args.cpu_sample_instances, os.cpu_count() or 1)
+            except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU number
+                cpu = dict(error=str(e))
+        out = {
+            "metric": "Gmeshlets/s culled (whole node), 100M meshlets", "value": round(value, 3), "unit": "Gmeshlets/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: synthetic {n_total} unique meshlets ({spec.num_instances} instances x {spec.meshlets_lod0}), "
+                                   "2-phase frustum+HZB+cone cull, 3840x2160 -> 2048x2048 R16F HZB, instances sharded over ranks"
+                                   + (" + RCCL all-gather of visible lists" if world > 1 else ""),
+                       "meshlets_in_scene": n_total, "meshlets_tested_per_frame": tested_all, "groups_per_frame": groups_all,
+                       "visible_per_frame": visible_all, "culling_flags": 7},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+    sync()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    drv.release()
+    gs.release()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def gs_num_meshlets(spec, recs) -> int:
+    """Meshlets tested by a record list: every LOD0 group of spec.meshlets_lod0 meshlets is full but the last."""
+    if len(recs) == 0:
+        return 0
+    off = recs["m_MeshletGroupOffset"].astype(np.int64)
+    return int(np.minimum(32, spec.meshlets_lod0 - off).clip(min=0).sum())
+
+
+if __name__ == "__main__":
+    main()

@@ -253,6 +253,15 @@ __global__ __launch_bounds__(kBlock) void visExpandKernel(MeshletCullArgs a)
     }
 }
 
+// Multi-GPU: a rank's list entries address its own records; before the all-gather each rank adds
+// the number of groups of the lower ranks so that (g << 5) | lane indexes the rank-major
+// concatenation of the record arrays (= the single-GPU canonical order).
+__global__ __launch_bounds__(256) void rebaseVisibleListKernel(uint32_t* list, const uint32_t* drawArgs, uint32_t capacity, uint32_t add)
+{
+    const uint32_t n = drawArgs[0] < capacity ? drawArgs[0] : capacity;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) list[i] += add;
+}
+
 template <bool F, bool O, bool C>
 void launchCull(const MeshletCullArgs& a, uint32_t grid, hipStream_t s)
 {
@@ -347,6 +356,28 @@ int recordASMain(trhip::DispatchCtx& ctx)
     return TRHIP_OK;
 }
 
+int recordRebase(trhip::DispatchCtx& ctx)
+{
+    const uint32_t* groupBase = (const uint32_t*)ctx.constants(0, 4);
+    trhip_buffer_t* list = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 0);
+    trhip_buffer_t* drawArgs = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 0);
+    TRHIP_REQUIRE(groupBase && list && drawArgs, "%s: needs push constant {groupBase}, UAV u0 (visible list), SRV t0 (draw args)", ctx.shaderName);
+    TRHIP_REQUIRE(drawArgs->byteSize >= 12, "%s: draw args smaller than 12 bytes", ctx.shaderName);
+    TRHIP_REQUIRE(*groupBase < (1u << 27), "%s: group base %u does not fit (g << 5)", ctx.shaderName, *groupBase);
+    uint32_t* lp = (uint32_t*)list->ptr;
+    const uint32_t* dp = (const uint32_t*)drawArgs->ptr;
+    const uint64_t cap64 = list->byteSize / 4;
+    const uint32_t cap = cap64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap64;
+    const uint32_t add = *groupBase << 5;
+    uint32_t grid = ctx.computeUnits() * 4u;
+    if (grid == 0) grid = 1;
+    ctx.emit("main", [=](hipStream_t s) {
+        hipLaunchKernelGGL(rebaseVisibleListKernel, dim3(grid), dim3(256), 0, s, lp, dp, cap, add);
+        return trhip::launchStatus("rebaseVisibleListKernel"); });
+    return TRHIP_OK;
+}
+
+trhip::ShaderRegistrar rr("visibility_CS_RebaseVisibleList", recordRebase, 0);
 trhip::ShaderRegistrar r0("basepass_AS_Main LATE_CULL=0", recordASMain, 0);
 trhip::ShaderRegistrar r1("basepass_AS_Main LATE_CULL=1", recordASMain, 1);
 trhip::ShaderRegistrar r2("basepass_AS_Main_cull", recordASMain, 0);

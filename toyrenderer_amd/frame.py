@@ -57,7 +57,9 @@ class FrameDriver:
     """BasePassRenderer (Setup + RenderBasePass) over rhi.  One command list per frame."""
 
     def __init__(self, dev: rhi.Device, scene: GpuScene, view, *, record_capacity: int, list_capacity: int | None = None,
-                 culling_flags: int = 7, force_mesh_lod: int = -1, freeze_culling_camera: bool = False):
+                 culling_flags: int = 7, force_mesh_lod: int = -1, freeze_culling_camera: bool = False, alloc=None):
+        """alloc(nbytes, name, stride, indirect) -> rhi.Buffer or None: lets the caller own the memory of the
+        output buffers (e.g. torch tensors handed to RCCL, gather.py); None -> device allocation."""
         self.dev, self.scene, self.view = dev, scene, view
         self.flags = culling_flags & 7
         self.force_mesh_lod = force_mesh_lod
@@ -75,11 +77,18 @@ class FrameDriver:
         dev.execute(init); dev.wait_idle(); init.release()
         # BasePassRenderer::Setup (:223-296); one set of outputs per pass slot (DESIGN.md "Outputs")
         n = max(scene.numInstances, 1)
-        self.records = [dev.create_buffer(12 * self.record_capacity, "MeshletAmplificationDataBuffer", stride=12) for _ in range(4)]
-        self.dispatchArgs = [dev.create_buffer(16, "MeshletDispatchArgumentsBuffer", stride=16, indirect=True) for _ in range(4)]
-        self.visMask = [dev.create_buffer(4 * self.record_capacity, "MeshletVisibilityMaskBuffer") for _ in range(4)]
-        self.visibleList = [dev.create_buffer(4 * max(self.list_capacity, 1), "VisibleMeshletListBuffer") for _ in range(4)]
-        self.drawArgs = [dev.create_buffer(12, "VisibleMeshletDrawArgsBuffer", stride=12, indirect=True) for _ in range(4)]
+
+        def mk(nbytes, name, stride=4, indirect=False):
+            b = alloc(nbytes, name, stride, indirect) if alloc is not None else None
+            return b if b is not None else dev.create_buffer(nbytes, name, stride=stride, indirect=indirect)
+        # slots 2,3 (alpha-mask lists) are only materialised when the scene has alpha-mask primitives
+        slots = 4 if scene.numAlphaMask else 2
+        self.records = [mk(12 * self.record_capacity, f"MeshletAmplificationDataBuffer{s}", 12) for s in range(slots)]
+        self.dispatchArgs = [mk(16, f"MeshletDispatchArgumentsBuffer{s}", 16, True) for s in range(slots)]
+        self.visMask = [mk(4 * self.record_capacity, f"MeshletVisibilityMaskBuffer{s}") for s in range(slots)]
+        self.visibleList = [mk(4 * max(self.list_capacity, 1), f"VisibleMeshletListBuffer{s}") for s in range(slots)]
+        self.drawArgs = [mk(12, f"VisibleMeshletDrawArgsBuffer{s}", 12, True) for s in range(slots)]
+        self.num_slots = slots
         self.lateArgs = dev.create_buffer(12, "LateCullDispatchIndirectArgs", stride=12, indirect=True)
         self.lateCount = dev.create_buffer(4, "LateCullInstanceCountBuffer")
         self.lateIds = dev.create_buffer(4 * n, "LateCullInstanceIDsBuffer")
@@ -214,7 +223,7 @@ class FrameDriver:
         self.dev.wait_idle()
         out = {}
         for s in range(4):
-            if not self.ran[s]:
+            if s >= self.num_slots or not self.ran[s]:
                 out[s] = None
                 continue
             args = self.dispatchArgs[s].download(np.uint32, 4)
