@@ -59,6 +59,15 @@ def build_shard(spec: synth.SceneSpec, rank: int, world: int, dev, threads: int 
     end = int(md["m_MeshLODDatas"]["m_MeshletDataBufferIdx"][i1 - 1, 0]) + int(md["m_MeshLODDatas"]["m_NumMeshlets"][i1 - 1].sum())
     n_local = end - base
     inst = synth.gen_instances(spec)
+    if os.environ.get("TR_EXPERIMENT_SORT_INSTANCES"):   # locality upper-bound experiment only (not the benchmark config)
+        w = inst["m_WorldMatrix"]
+        z = -np.minimum(w[:, 3, 2], -1e-3)
+        tx = np.clip(((w[:, 3, 0] / z * 1.358) * 0.5 + 0.5) * 32, 0, 31).astype(np.int64)
+        ty = np.clip(((w[:, 3, 1] / z * 2.414) * -0.5 + 0.5) * 32, 0, 31).astype(np.int64)
+        order = np.argsort(ty * 32 + tx, kind="stable")
+        keep_mesh = inst["m_MeshDataIdx"].copy()
+        inst = inst[order]
+        inst["m_MeshDataIdx"] = keep_mesh
     # rebase the owned meshes' meshlet indices into the local shard
     md_local = md.copy()
     lods = md_local["m_MeshLODDatas"]
@@ -121,6 +130,7 @@ def main():
     ap.add_argument("--cpu-sample-instances", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--flags", type=int, default=7, help="culling flags (7 = frustum+occlusion+cone, the headline config)")
     args = ap.parse_args()
 
     import torch
@@ -149,7 +159,7 @@ def main():
     record_cap = (i1 - i0) * groups_per_instance + 1
 
     gather = VisibleListGather(dev, dist, world, rank, record_cap, record_cap * 32) if world > 1 else None
-    drv = FrameDriver(dev, gs, view, record_capacity=record_cap, list_capacity=record_cap * 32, culling_flags=7,
+    drv = FrameDriver(dev, gs, view, record_capacity=record_cap, list_capacity=record_cap * 32, culling_flags=args.flags,
                       alloc=gather.alloc if gather else None)
     drv.depth.upload_mip(0, depth)
 
@@ -241,7 +251,7 @@ def main():
                                    "2-phase frustum+HZB+cone cull, 3840x2160 -> 2048x2048 R16F HZB, instances sharded over ranks"
                                    + (" + RCCL all-gather of visible lists" if world > 1 else ""),
                        "meshlets_in_scene": n_total, "meshlets_tested_per_frame": tested_all, "groups_per_frame": groups_all,
-                       "visible_per_frame": visible_all, "culling_flags": 7},
+                       "visible_per_frame": visible_all, "culling_flags": args.flags},
             "roofline": roofline, "cpu_baseline": cpu,
         }
     sync()

@@ -20,7 +20,13 @@ struct F3 { float x, y, z; };
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ float min_(float a, float b) { return __builtin_fminf(a, b); }
 __device__ __forceinline__ float max_(float a, float b) { return __builtin_fmaxf(a, b); }
+#ifdef TR_EXPERIMENT_FAST_MATH   // timing experiment only (results are NOT bit-exact): approximate sqrt / division
+__device__ __forceinline__ float sqrt_(float a) { return __builtin_amdgcn_sqrtf(a); }
+__device__ __forceinline__ float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+#else
 __device__ __forceinline__ float sqrt_(float a) { return __builtin_sqrtf(a); }
+__device__ __forceinline__ float div_(float a, float b) { return a / b; }
+#endif
 __device__ __forceinline__ float clamp_(float x, float lo, float hi) { return min_(max_(x, lo), hi); }
 
 __device__ __forceinline__ float dot3(F3 a, F3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
@@ -115,18 +121,31 @@ __device__ __forceinline__ float sampleHzbMin(const Hzb& h, float u, float v, in
     return min_(min_(min_(d00, d01), d10), d11);
 }
 
-// culling.hlsli:36-82; returns true = visible
-__device__ __forceinline__ bool occlusionVisible(F3 c, float r, float nearPlane, float P00, float P11, const Hzb& h)
+// culling.hlsli:36-82 split in two so that a kernel can issue the four texel loads, do unrelated
+// ALU work (the cone test) while they are in flight, and only then compare.  Evaluated for every
+// lane (no branch): the near-plane accept (:48-49) is carried as a flag, and NaN/inf from a sphere
+// that straddles the camera plane are absorbed by the clamps, so the addresses are always valid.
+struct OccSample
 {
-    if ((c.z - nearPlane) < r) return true;                          // :48-49
+    bool accept;              // sphere intersects the near plane -> visible (:48-49)
+    float depthSphere;        // :79
+    uint32_t i00, i01, i10, i11;   // texel indices relative to Hzb::base
+};
+
+// mipOff: the mip offset table (texels); the hot kernel passes a copy parked in LDS so that the
+// per-lane lookup is one ds_read instead of a select chain over kernel arguments.
+__device__ __forceinline__ OccSample occlusionPrepare(F3 c, float r, float nearPlane, float P00, float P11, const Hzb& h, const uint32_t* mipOff)
+{
+    OccSample o;
+    o.accept = (c.z - nearPlane) < r;                                // :48-49
     float crx = c.x * r, cry = c.y * r, crz = c.z * r;               // :53
     float czr2 = fma_(c.z, c.z, -(r * r));                           // :54
     float vx = sqrt_(fma_(c.x, c.x, czr2));                          // :56
-    float minx = fma_(vx, c.x, -crz) / fma_(vx, c.z, crx);           // :57
-    float maxx = fma_(vx, c.x, crz) / fma_(vx, c.z, -crx);           // :58
+    float minx = div_(fma_(vx, c.x, -crz), fma_(vx, c.z, crx));           // :57
+    float maxx = div_(fma_(vx, c.x, crz), fma_(vx, c.z, -crx));           // :58
     float vy = sqrt_(fma_(c.y, c.y, czr2));                          // :60
-    float miny = fma_(vy, c.y, -crz) / fma_(vy, c.z, cry);           // :61
-    float maxy = fma_(vy, c.y, crz) / fma_(vy, c.z, -cry);           // :62
+    float miny = div_(fma_(vy, c.y, -crz), fma_(vy, c.z, cry));           // :61
+    float maxy = div_(fma_(vy, c.y, crz), fma_(vy, c.z, -cry));           // :62
     float ax = clamp_(minx * P00, -1.0f, 1.0f);                      // :64-67
     float ay = clamp_(miny * P11, -1.0f, 1.0f);
     float az = clamp_(maxx * P00, -1.0f, 1.0f);
@@ -137,10 +156,43 @@ __device__ __forceinline__ bool occlusionVisible(F3 c, float r, float nearPlane,
     aw = fma_(aw, -0.5f, 0.5f);
     float width = (az - ax) * (float)h.width;                        // :73
     float height = (aw - ay) * (float)h.height;                      // :74
-    int level = hzbLevel(width, height, h.mips);                     // :75
-    float depth = sampleHzbMin(h, (ax + az) * 0.5f, (ay + aw) * 0.5f, level); // :78
-    float depthSphere = nearPlane / (c.z - r);                       // :79
-    return depthSphere >= depth;                                     // :81
+    int mip = hzbLevel(width, height, h.mips);                       // :75
+    float u = (ax + az) * 0.5f, v = (ay + aw) * 0.5f;                // :78
+    // SampleLevel footprint (see sampleHzbMin)
+    uint32_t mw = (h.width >> mip) ? (h.width >> mip) : 1u;
+    uint32_t mh = (h.height >> mip) ? (h.height >> mip) : 1u;
+    float fx = fma_(u, (float)mw, -0.5f);
+    float fy = fma_(v, (float)mh, -0.5f);
+    float flx = __builtin_floorf(fx), fly = __builtin_floorf(fy);
+    int x0 = (int)flx, y0 = (int)fly;
+    bool wx1 = (fx - flx) > 0.0f, wy1 = (fy - fly) > 0.0f;
+    int xm = (int)mw - 1, ym = (int)mh - 1;
+    int x1 = min(max(x0 + 1, 0), xm), y1 = min(max(y0 + 1, 0), ym);
+    x0 = min(max(x0, 0), xm);
+    y0 = min(max(y0, 0), ym);
+    x1 = wx1 ? x1 : x0;
+    y1 = wy1 ? y1 : y0;
+    uint32_t base = mipOff[mip];
+    o.i00 = base + (uint32_t)y0 * mw + (uint32_t)x0;
+    o.i01 = base + (uint32_t)y0 * mw + (uint32_t)x1;
+    o.i10 = base + (uint32_t)y1 * mw + (uint32_t)x0;
+    o.i11 = base + (uint32_t)y1 * mw + (uint32_t)x1;
+    o.depthSphere = div_(nearPlane, c.z - r);                           // :79
+    return o;
+}
+
+__device__ __forceinline__ bool occlusionResolve(const OccSample& o, float d00, float d01, float d10, float d11)
+{
+    float depth = min_(min_(min_(d00, d01), d10), d11);
+    return o.accept | (o.depthSphere >= depth);                      // :81
+}
+
+// culling.hlsli:36-82; returns true = visible
+__device__ __forceinline__ bool occlusionVisible(F3 c, float r, float nearPlane, float P00, float P11, const Hzb& h)
+{
+    if ((c.z - nearPlane) < r) return true;                          // :48-49
+    OccSample o = occlusionPrepare(c, r, nearPlane, P00, P11, h, h.mipOffset);
+    return occlusionResolve(o, (float)h.base[o.i00], (float)h.base[o.i01], (float)h.base[o.i10], (float)h.base[o.i11]);
 }
 
 // x / 255.0f for x in [0,255], correctly rounded (== IEEE division; verified exhaustively by
@@ -163,7 +215,7 @@ __device__ __forceinline__ bool coneBackfacing(uint32_t packed, F3 cv, float r, 
     F3 a = { fma_(q0, 2.0f, -1.0f), fma_(q1, 2.0f, -1.0f), fma_(q2, 2.0f, -1.0f) };
     F3 t = mulVec(a, adj0, adj1, adj2);
     float len = sqrt_(dot3(t, t));
-    t = { t.x / len, t.y / len, t.z / len };                         // normalize = v / length
+    t = { div_(t.x, len), div_(t.y, len), div_(t.z, len) };                         // normalize = v / length
     F3 axis = mulVec(t, view.r0, view.r1, view.r2);
     axis.z = -axis.z;
     return dot3(cv, axis) >= fma_(cutoff, sqrt_(dot3(cv, cv)), r);

@@ -14,15 +14,22 @@
 //
 // This is the hot kernel of the path: HBM-bound streaming of MeshletData (32 B per meshlet
 // tested, algorithmic).  Structure for CDNA4:
-//   * a workgroup (256 threads = 4 wave64) owns a chunk of kChunk consecutive records;
-//   * prologue: one thread per record resolves record -> instance -> MeshData LOD entry (the
-//     three dependent loads of basepass.hlsl:54-58) ONCE per record, computes the per-record
-//     invariants (max scale, adjugate) and parks them in LDS;
-//   * main loop: a wave64 runs two records per step (lanes 0-31 / 32-63); per-record data comes
-//     from LDS as broadcast reads, so the only HBM stream is one coalesced 16-B (+4-B) load per
-//     lane; the next step's loads are issued before the current step's ALU work;
-//   * the 64-bit ballot is the two groups' visibility masks; masks are written once per chunk,
-//     together with the chunk's popcount (consumed by the scan/expand kernels below).
+//   * the unit of work is a BATCH of 64 consecutive records owned by ONE wave64 (no workgroup
+//     barriers anywhere): lane l resolves record l -> instance -> MeshData LOD entry (the three
+//     dependent loads of basepass.hlsl:54-58) once per record, computes the per-record
+//     invariants (max scale, adjugate) and parks them in the wave's private LDS slice;
+//   * main loop, 32 steps: the wave runs two records per step (lanes 0-31 / 32-63); per-record
+//     data are LDS broadcast reads, so the only HBM stream is one 16-B + one 4-B load per lane;
+//     meshlet data are prefetched TWO steps ahead into a two-slot register ring;
+//   * every test is evaluated branch-free and the result is the AND (the tests are pure, so this
+//     equals the reference's short-circuit order :73-108).  That lets the four HZB texel loads be
+//     issued before the next prefetch and before the cone test: vmcnt is in-order, so the texels
+//     can be awaited with the younger prefetch still in flight, and their latency hides under the
+//     cone test's ALU work;
+//   * the 64-bit ballot is the two groups' visibility masks (WaveActiveCountBits/WavePrefix-
+//     CountBits :116-120); masks and the batch popcount are written once per batch.
+#include <type_traits>
+
 #include "cull_math.hip.h"
 #include "trhip_internal.h"
 
@@ -32,9 +39,9 @@ namespace
 {
 
 constexpr uint32_t kBlock = 256;
-constexpr uint32_t kChunk = 128;                 // records per workgroup iteration
-constexpr uint32_t kRecordsPerStep = kBlock / 32;
-constexpr uint32_t kStepsPerChunk = kChunk / kRecordsPerStep;
+constexpr uint32_t kWaves = kBlock / 64;
+constexpr uint32_t kBatch = 64;                  // records per wave batch
+constexpr uint32_t kSteps = kBatch / 2;          // two records per wave step
 
 struct RecordInfo                                 // per-record invariants parked in LDS (96 B)
 {
@@ -61,8 +68,8 @@ struct MeshletCullArgs
     uint32_t* visibleList; uint32_t listCapacity;
     uint32_t* drawArgs;
     // scratch
-    uint32_t* chunkSum;                           // per chunk: visible meshlets -> exclusive prefix after scan
-    uint32_t maxChunks;
+    uint32_t* batchSum;                           // per batch: visible meshlets -> exclusive prefix after scan
+    uint32_t maxBatches;
 };
 
 __device__ __forceinline__ uint32_t groupCount(const MeshletCullArgs& a)
@@ -74,40 +81,58 @@ __device__ __forceinline__ uint32_t groupCount(const MeshletCullArgs& a)
 
 struct MeshletRegs { float4 sphere; uint32_t cone; };
 
-__device__ __forceinline__ MeshletRegs loadMeshlet(const MeshletData* meshlets, uint32_t idx, bool active)
+// Every lane always loads (inactive lanes re-read a valid meshlet of the record, or meshlet 0):
+// with no exec-masked or conditional loads in the loop the compiler can count outstanding loads
+// exactly and emits partial s_waitcnt vmcnt(N) instead of vmcnt(0).
+__device__ __forceinline__ MeshletRegs loadMeshlet(const MeshletData* meshlets, uint32_t base, uint32_t count, uint32_t sub)
 {
+    const uint32_t last = count ? count - 1u : 0u;
+    const uint32_t idx = count ? base + (sub < last ? sub : last) : 0u;
+    const MeshletData* p = meshlets + idx;
     MeshletRegs m;
-    m.sphere = make_float4(0.f, 0.f, 0.f, 0.f);
-    m.cone = 0;
-    if (active) {
-        const MeshletData* p = meshlets + idx;
-        m.sphere = *reinterpret_cast<const float4*>(p);                              // basepass.hlsl:65
-        m.cone = p->m_ConeAxisAndCutoff;
-    }
+    m.sphere = *reinterpret_cast<const float4*>(p);                                  // basepass.hlsl:65
+    m.cone = p->m_ConeAxisAndCutoff;
     return m;
 }
 
 template <bool FRUSTUM, bool OCCLUSION, bool CONE>
 __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
 {
-    __shared__ RecordInfo s_rec[kChunk];
-    __shared__ uint32_t s_mask[kChunk];
-    __shared__ uint32_t s_wavePop[kBlock / 64];
+    __shared__ RecordInfo s_recAll[kWaves][kBatch];
+    __shared__ uint32_t s_gIdxAll[kWaves][kBatch];
+    __shared__ uint32_t s_mipOff[16];
 
     const uint32_t G = groupCount(a);
-    const uint32_t numChunks = (G + kChunk - 1) / kChunk;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t half = lane >> 5, sub = lane & 31u;
     const cm::M43 V = cm::loadM43(a.k.m_WorldToView);
+    RecordInfo* s_rec = s_recAll[wave];
+    uint32_t* s_gIdx = s_gIdxAll[wave];
 
-    for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
-        const uint32_t g0 = chunk * kChunk;
-        __syncthreads();                                                             // previous chunk's LDS reads done
-        // ---- prologue: resolve the chunk's records (basepass.hlsl:52-58) --------------------
-        if (tid < kChunk) {
+    if (tid < 16) s_mipOff[tid] = a.hzb.mipOffset[tid];
+    __syncthreads();                                                                 // the only workgroup barrier
+
+    // Work decomposition: the record list is cut into SUPER-BATCHES of 64 * numWaves records; inside
+    // one, wave w runs records {2*numWaves*s + 2*w + half} at step s.  All waves of the chip thus
+    // walk a moving window of ~2*numWaves consecutive records (instead of numWaves windows 64 records
+    // apart), which keeps the HZB texels touched at any one time close together (L2/L1 locality).
+    const uint32_t numWaves = gridDim.x * kWaves;
+    const uint32_t waveId = blockIdx.x * kWaves + wave;
+    const uint32_t superSize = numWaves * kBatch;
+    const uint32_t numSuper = (G + superSize - 1) / superSize;
+    for (uint32_t sb = 0; sb < numSuper; ++sb) {
+        const uint32_t sbBase = sb * superSize;
+        if (sbBase + 2 * waveId >= G) break;                                         // nothing left for this wave
+        // ---- prologue: lane l resolves the record of step l/2, half l&1 (basepass.hlsl:52-58) ---
+        {
             RecordInfo ri;
             ri.count = 0; ri.meshletBase = 0; ri.maxScale = 0.f;
-            const uint32_t g = g0 + tid;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) ri.w[i] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) ri.adj[i] = 0.f;
+            const uint32_t g = sbBase + (lane >> 1) * 2 * numWaves + 2 * waveId + (lane & 1);
+            s_gIdx[lane] = g;
             if (g < G) {
                 const MeshletAmplificationData rec = a.records[g];
                 const BasePassInstanceConstants& inst = a.instances[rec.m_InstanceConstIdx];
@@ -136,117 +161,142 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
                 ri.count = cnt;
                 ri.meshletBase = (uint32_t)base;
             }
-            s_rec[tid] = ri;
+            s_rec[lane] = ri;
         }
-        __syncthreads();
+        // LDS traffic of one wave is executed in order: the wave-level fence only stops the
+        // compiler from moving the reads below above the writes above.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        // ---- main loop: two records per wave per step ----------------------------------------
-        uint32_t wavePop = 0;
-        uint32_t r = wave * 2 + half;                                                // record within the chunk
-        MeshletRegs cur = loadMeshlet(a.meshlets, s_rec[r].meshletBase + sub, sub < s_rec[r].count);
-#pragma unroll 1
-        for (uint32_t step = 0; step < kStepsPerChunk; ++step) {
-            const uint32_t rn = r + kRecordsPerStep;
-            MeshletRegs nxt;
-            if (step + 1 < kStepsPerChunk)
-                nxt = loadMeshlet(a.meshlets, s_rec[rn].meshletBase + sub, sub < s_rec[rn].count);
+        // ---- main loop: two records per step, meshlet data two steps ahead ----------------------
+        MeshletRegs slotA = loadMeshlet(a.meshlets, s_rec[half].meshletBase, s_rec[half].count, sub);
+        MeshletRegs slotB = loadMeshlet(a.meshlets, s_rec[2 + half].meshletBase, s_rec[2 + half].count, sub);
 
+        auto step = [&](MeshletRegs& slot, uint32_t s, auto prefetch) {
+            const uint32_t r = 2 * s + half;                                         // record within the batch
             const RecordInfo& ri = s_rec[r];
+            const float4 sphere = slot.sphere;
+            const uint32_t cone = slot.cone;
             bool vis = sub < ri.count;
-            if (vis) {
-                const cm::M43 W = { { ri.w[0], ri.w[1], ri.w[2] }, { ri.w[3], ri.w[4], ri.w[5] },
-                                    { ri.w[6], ri.w[7], ri.w[8] }, { ri.w[9], ri.w[10], ri.w[11] } };
-                const cm::F3 cw = cm::mulPoint({ cur.sphere.x, cur.sphere.y, cur.sphere.z }, W);   // :67
-                const cm::F3 cv = cm::toView(cw, V);                                               // :68-69
-                const float rad = cur.sphere.w * ri.maxScale;                                      // :71
-                if (FRUSTUM)
-                    vis = cm::frustumVisible(cv, rad, a.k.m_Frustum.x, a.k.m_Frustum.y, a.k.m_Frustum.z, a.k.m_Frustum.w); // :73
-                if (OCCLUSION && vis)
-                    vis = cm::occlusionVisible(cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb);    // :75-88 (Q4)
-                if (CONE && vis)
-                    vis = !cm::coneBackfacing(cur.cone, cv, rad, { ri.adj[0], ri.adj[1], ri.adj[2] },
-                                              { ri.adj[3], ri.adj[4], ri.adj[5] }, { ri.adj[6], ri.adj[7], ri.adj[8] }, V); // :90-108
+            const cm::M43 W = { { ri.w[0], ri.w[1], ri.w[2] }, { ri.w[3], ri.w[4], ri.w[5] },
+                                { ri.w[6], ri.w[7], ri.w[8] }, { ri.w[9], ri.w[10], ri.w[11] } };
+            const cm::F3 cw = cm::mulPoint({ sphere.x, sphere.y, sphere.z }, W);                   // :67
+            const cm::F3 cv = cm::toView(cw, V);                                                   // :68-69
+            const float rad = sphere.w * ri.maxScale;                                              // :71
+            if (FRUSTUM)
+                vis &= cm::frustumVisible(cv, rad, a.k.m_Frustum.x, a.k.m_Frustum.y, a.k.m_Frustum.z, a.k.m_Frustum.w); // :73
+            cm::OccSample os;
+            _Float16 t00 = 0, t01 = 0, t10 = 0, t11 = 0;
+            if (OCCLUSION) {                                                                       // :75-88 (Q4)
+                os = cm::occlusionPrepare(cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_mipOff);
+                t00 = a.hzb.base[os.i00]; t01 = a.hzb.base[os.i01];
+                t10 = a.hzb.base[os.i10]; t11 = a.hzb.base[os.i11];
             }
+            if (decltype(prefetch)::value) {                                                       // prefetch step s+2 into this slot
+                const uint32_t rn = r + 4;
+                slot = loadMeshlet(a.meshlets, s_rec[rn].meshletBase, s_rec[rn].count, sub);
+            }
+            if (CONE)                                                                              // :90-108
+                vis &= !cm::coneBackfacing(cone, cv, rad, { ri.adj[0], ri.adj[1], ri.adj[2] },
+                                           { ri.adj[3], ri.adj[4], ri.adj[5] }, { ri.adj[6], ri.adj[7], ri.adj[8] }, V);
+            if (OCCLUSION)
+                vis &= cm::occlusionResolve(os, (float)t00, (float)t01, (float)t10, (float)t11);
             const unsigned long long ballot = __ballot(vis);                        // :116,120 WavePrefix/ActiveCountBits
-            if (sub == 0) s_mask[r] = (uint32_t)(ballot >> (half * 32));
-            wavePop += (uint32_t)__popcll(ballot);
-            cur = nxt;
-            r = rn;
+            if (sub == 0) {
+                const uint32_t g = s_gIdx[r];
+                if (g < G) a.visMask[g] = (uint32_t)(ballot >> (half * 32));
+            }
+        };
+#pragma unroll 1
+        for (uint32_t s = 0; s < kSteps - 2; s += 2) {
+            step(slotA, s, std::true_type{});
+            step(slotB, s + 1, std::true_type{});
         }
-        if (lane == 0) s_wavePop[wave] = wavePop;
-        __syncthreads();
-        if (tid < kChunk && g0 + tid < G) a.visMask[g0 + tid] = s_mask[tid];
-        if (tid == 0) a.chunkSum[chunk] = s_wavePop[0] + s_wavePop[1] + s_wavePop[2] + s_wavePop[3];
+        step(slotA, kSteps - 2, std::false_type{});
+        step(slotB, kSteps - 1, std::false_type{});
     }
 }
 
-// One block: exclusive scan of the chunk sums -> list offsets; total -> drawArgs.
+// Visible meshlets per batch of 64 consecutive records (canonical order): one wave per batch.
+__global__ __launch_bounds__(kBlock) void visCountKernel(MeshletCullArgs a)
+{
+    const uint32_t G = groupCount(a);
+    const uint32_t numBatches = (G + kBatch - 1) / kBatch;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t batch = blockIdx.x * kWaves + wave; batch < numBatches; batch += gridDim.x * kWaves) {
+        const uint32_t g = batch * kBatch + lane;
+        uint32_t pc = g < G ? (uint32_t)__popc(a.visMask[g]) : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) pc += __shfl_xor(pc, d);
+        if (lane == 0) a.batchSum[batch] = pc;
+    }
+}
+
+__device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t n = __shfl_up(v, d);
+        if (lane >= (uint32_t)d) v += n;
+    }
+    return v;
+}
+
+// One block: exclusive scan of the batch sums -> list offsets; total -> drawArgs.
+// Tiles of 1024 with a carry; a tile = wave scans + one LDS exchange (two barriers).
 __global__ __launch_bounds__(1024) void visScanKernel(MeshletCullArgs a)
 {
-    __shared__ uint32_t s_v[1024];
-    __shared__ uint32_t s_carry;
+    __shared__ uint32_t s_wave[16];
     const uint32_t G = groupCount(a);
-    const uint32_t numChunks = (G + kChunk - 1) / kChunk;
-    const uint32_t tid = threadIdx.x;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < numChunks; base += 1024) {
+    const uint32_t numBatches = (G + kBatch - 1) / kBatch;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < numBatches; base += 1024) {
         const uint32_t i = base + tid;
-        const uint32_t v = i < numChunks ? a.chunkSum[i] : 0u;
-        s_v[tid] = v;
+        const uint32_t v = i < numBatches ? a.batchSum[i] : 0u;
+        const uint32_t inc = waveInclusiveScan(v, lane);
+        if (lane == 63) s_wave[wave] = inc;
         __syncthreads();
-        for (uint32_t d = 1; d < 1024; d <<= 1) {
-            uint32_t p = tid >= d ? s_v[tid - d] : 0u;
-            __syncthreads();
-            s_v[tid] += p;
-            __syncthreads();
+        uint32_t pre = 0, tot = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16; ++w) {
+            const uint32_t x = s_wave[w];
+            if (w < wave) pre += x;
+            tot += x;
         }
-        if (i < numChunks) a.chunkSum[i] = s_carry + s_v[tid] - v;
-        __syncthreads();
-        if (tid == 1023) s_carry += s_v[1023];
+        if (i < numBatches) a.batchSum[i] = carry + pre + inc - v;
+        carry += tot;
         __syncthreads();
     }
     if (tid == 0) {
-        a.drawArgs[0] = s_carry;       // replaces DispatchMesh(numVisible,1,1) summed over groups (basepass.hlsl:120-121)
+        a.drawArgs[0] = carry;         // replaces DispatchMesh(numVisible,1,1) summed over groups (basepass.hlsl:120-121)
         a.drawArgs[1] = 1;
         a.drawArgs[2] = 1;
     }
 }
 
-// Ordered compaction: one thread per (group, lane) slot; a visible slot's position is the chunk
-// offset + popcounts of the earlier groups of its chunk + WavePrefixCountBits inside its group.
+// Ordered compaction, one wave per batch: lane l holds the mask of record l, a wave scan gives
+// the record offsets, then one thread per (group, lane) slot: a visible slot's position is the
+// batch offset + popcounts of the earlier groups of its batch + WavePrefixCountBits in its group.
 __global__ __launch_bounds__(kBlock) void visExpandKernel(MeshletCullArgs a)
 {
-    __shared__ uint32_t s_mask[kChunk];
-    __shared__ uint32_t s_off[kChunk];
     const uint32_t G = groupCount(a);
-    const uint32_t numChunks = (G + kChunk - 1) / kChunk;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    for (uint32_t chunk = blockIdx.x; chunk < numChunks; chunk += gridDim.x) {
-        const uint32_t g0 = chunk * kChunk;
-        __syncthreads();
-        if (tid < kChunk) s_mask[tid] = g0 + tid < G ? a.visMask[g0 + tid] : 0u;
-        __syncthreads();
-        if (tid < 64) {                                   // wave 0: exclusive scan of 128 popcounts, 2 per lane
-            const uint32_t p0 = (uint32_t)__popc(s_mask[2 * lane]), p1 = (uint32_t)__popc(s_mask[2 * lane + 1]);
-            uint32_t inc = p0 + p1;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                uint32_t n = __shfl_up(inc, d);
-                if (lane >= (uint32_t)d) inc += n;
-            }
-            const uint32_t exc = inc - (p0 + p1);
-            s_off[2 * lane] = exc;
-            s_off[2 * lane + 1] = exc + p0;
-        }
-        __syncthreads();
-        const uint32_t chunkBase = a.chunkSum[chunk];
-        for (uint32_t step = 0; step < kStepsPerChunk; ++step) {
-            const uint32_t r = step * kRecordsPerStep + (tid >> 5);
-            const uint32_t sub = tid & 31u;
-            const uint32_t m = s_mask[r];
+    const uint32_t numBatches = (G + kBatch - 1) / kBatch;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t half = lane >> 5, sub = lane & 31u;
+    for (uint32_t batch = blockIdx.x * kWaves + wave; batch < numBatches; batch += gridDim.x * kWaves) {
+        const uint32_t g0 = batch * kBatch;
+        const uint32_t mask = g0 + lane < G ? a.visMask[g0 + lane] : 0u;
+        const uint32_t pc = (uint32_t)__popc(mask);
+        const uint32_t exc = waveInclusiveScan(pc, lane) - pc + a.batchSum[batch];
+#pragma unroll 4
+        for (uint32_t s = 0; s < kSteps; ++s) {
+            const uint32_t r = 2 * s + half;
+            const uint32_t m = __shfl(mask, r);
+            const uint32_t off = __shfl(exc, r);
             if (m & (1u << sub)) {
-                const uint32_t pos = chunkBase + s_off[r] + (uint32_t)__popc(m & ((1u << sub) - 1u));
+                const uint32_t pos = off + (uint32_t)__popc(m & ((1u << sub) - 1u));
                 if (pos < a.listCapacity) a.visibleList[pos] = ((g0 + r) << 5) | sub;
             }
         }
@@ -325,14 +375,15 @@ int recordASMain(trhip::DispatchCtx& ctx)
     const uint64_t lcap = visList->byteSize / 4;
     a.listCapacity = lcap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)lcap;
     a.drawArgs = (uint32_t*)drawArgs->ptr;
-    a.maxChunks = (a.recordCapacity + kChunk - 1) / kChunk;
-    a.chunkSum = (uint32_t*)ctx.scratch((size_t)a.maxChunks * 4);
-    TRHIP_REQUIRE(a.chunkSum, "%s: scratch allocation failed", ctx.shaderName);
+    a.maxBatches = (a.recordCapacity + kBatch - 1) / kBatch;
+    a.batchSum = (uint32_t*)ctx.scratch((size_t)a.maxBatches * 4);
+    TRHIP_REQUIRE(a.batchSum, "%s: scratch allocation failed", ctx.shaderName);
 
     // Persistent grid: the group count lives on the device (indirect), so launch enough
     // workgroups to fill the chip and let them stride over the chunks.
-    uint32_t grid = ctx.computeUnits() * 8u;
-    if (grid > a.maxChunks) grid = a.maxChunks;
+    uint32_t grid = ctx.computeUnits() * 6u;       // 6 workgroups per CU are resident (25.6 KB LDS each)
+    const uint32_t needBlocks = (a.maxBatches + kWaves - 1) / kWaves;
+    if (grid > needBlocks) grid = needBlocks;
     if (grid == 0) grid = 1;
     const uint32_t flags = k->m_CullingFlags & 7u;
     ctx.emit("cull", [a, grid, flags](hipStream_t s) {
@@ -347,6 +398,9 @@ int recordASMain(trhip::DispatchCtx& ctx)
         default: launchCull<true, true, true>(a, grid, s); break;
         }
         return trhip::launchStatus("meshletCullKernel"); });
+    ctx.emit("count", [a, grid](hipStream_t s) {
+        hipLaunchKernelGGL(visCountKernel, dim3(grid), dim3(kBlock), 0, s, a);
+        return trhip::launchStatus("visCountKernel"); });
     ctx.emit("scan", [a](hipStream_t s) {
         hipLaunchKernelGGL(visScanKernel, dim3(1), dim3(1024), 0, s, a);
         return trhip::launchStatus("visScanKernel"); });

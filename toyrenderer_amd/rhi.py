@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtrhip.so")
+LIB_PATH = os.environ.get("TRHIP_LIB") or os.path.join(_HERE, "lib", "libtrhip.so")   # TRHIP_LIB: experiment builds only
 
 FORMAT_R16_FLOAT = 1
 FORMAT_R32_FLOAT = 2
