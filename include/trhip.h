@@ -147,6 +147,9 @@ int  trhip_cmd_close(trhip_cmdlist cl);                               /* ::close
 int  trhip_cmd_write_buffer(trhip_cmdlist cl, trhip_buffer buf, uint64_t dst_offset, const void* src, uint64_t bytes);
 int  trhip_cmd_clear_buffer_u32(trhip_cmdlist cl, trhip_buffer buf, uint32_t value);   /* ::clearBufferUInt   */
 int  trhip_cmd_clear_texture_f32(trhip_cmdlist cl, trhip_texture tex, float value);    /* ::clearTextureFloat */
+int  trhip_cmd_copy_buffer(trhip_cmdlist cl, trhip_buffer dst, uint64_t dst_offset, trhip_buffer src, uint64_t src_offset, uint64_t bytes); /* ::copyBuffer */
+/* ::copyTexture, whole mip chain; both textures must have identical dimensions, mips and format. */
+int  trhip_cmd_copy_texture(trhip_cmdlist cl, trhip_texture dst, trhip_texture src);
 /* ::setComputeState + ::setPushConstants + ::dispatch(gx,gy,gz) (Graphic.cpp:893-947).
  * Group counts keep the reference's meaning (groups of the HLSL [numthreads]); the HIP launch
  * shape behind a shader name is the back end's business. */

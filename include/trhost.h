@@ -1,0 +1,80 @@
+/*
+ * trhost.h -- C entry points of the C++ host mirror (toyrenderer_amd/csrc/host): the reference's
+ * frame loop for the visibility path (Graphic::Update -> Scene::Update -> RenderGraph::AddRenderer /
+ * Compile -> UpdateInstanceConstsRenderer / GBufferRenderer -> Graphic::AddComputePass) behind a
+ * plain-C facade, for callers that cannot link C++ (Python tests, bench.py).  A C++ application
+ * uses the classes directly.
+ *
+ * All functions return 0 on success, -1 on failure (text: trhost_last_error()).  One context per
+ * process (the reference's Graphic / Scene are singletons: Graphic.h:43, Scene.h:179).
+ */
+#ifndef TRHOST_H_
+#define TRHOST_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* trhost_last_error(void);
+
+/* Graphic::Initialize (Graphic.cpp:608-647): device, shaders(kernels), common resources, renderers'
+ * Initialize() (HZB creation, BasePassRenderers.cpp:596-616).  external_hip_stream may be NULL. */
+int  trhost_initialize(int device_index, uint32_t render_width, uint32_t render_height, void* external_hip_stream);
+void trhost_shutdown(void);
+
+/* Scene content as flat arrays in the wire formats of ShaderInterop.h (what SceneLoading.cpp:203-224,
+ * 1016-1088 and Scene.cpp:282-362 produce); followed by Graphic::PostSceneLoad. */
+int  trhost_load_scene(const void* instances, uint32_t num_instances, const void* mesh_data, uint32_t num_meshes,
+                       const void* meshlets, uint64_t num_meshlets, const uint32_t* opaque_ids, uint32_t num_opaque,
+                       const uint32_t* alpha_mask_ids, uint32_t num_alpha_mask);
+/* Node hierarchy for UpdateInstanceConstsRenderer (BasePassRenderers.cpp:64-104); enables the pass. */
+int  trhost_load_nodes(const void* node_local_transforms, uint32_t num_nodes, const uint32_t* primitive_to_node);
+int  trhost_set_node_transforms(const void* node_local_transforms, uint32_t num_nodes);
+
+/* View (Scene.cpp:109-145): row-major 4x4, row vectors.  prev_world_to_view / view_to_clip may be NULL
+ * (previous = last frame's; projection = RH reverse-Z infinite from fov/aspect/near). */
+int  trhost_set_camera(const float* world_to_view, const float* prev_world_to_view, const float* view_to_clip, float near_plane);
+/* Scene.h:128-132 toggles; force_mesh_lod < 0 = automatic. */
+int  trhost_set_culling(int frustum, int occlusion, int cone, int freeze_culling_camera, int force_mesh_lod);
+/* Capacity of the amplification-record buffer (kMaxThreadGroupsPerDimension = 65535 in the reference)
+ * and the per-resource cap of the render graph (1 GB in the reference); 0 keeps the current value. */
+int  trhost_set_limits(uint32_t max_meshlet_groups, uint64_t max_transient_resource_bytes);
+
+/* Depth image the next frames' GenerateHZB will consume (stand-in for the rasteriser). */
+int  trhost_upload_depth(const float* depth, uint32_t width, uint32_t height);
+int  trhost_upload_hzb_mip(uint32_t mip, const uint16_t* texels, uint64_t bytes);
+int  trhost_download_hzb_mip(uint32_t mip, uint16_t* texels, uint64_t bytes);
+int  trhost_hzb_info(uint32_t* width, uint32_t* height, uint32_t* mips);
+
+int  trhost_frame(void);       /* Graphic::Update: record every pass, submit, (asynchronous)       */
+int  trhost_wait_idle(void);
+
+typedef struct {
+    int   ran;
+    void* records;        /* trhip_buffer handles (include/trhip.h) of the pass slot's outputs      */
+    void* dispatch_args;
+    void* vis_mask;
+    void* visible_list;
+    void* draw_args;
+    void* late_count;
+    void* late_args;
+} trhost_pass_buffers_t;
+/* slot: 0 early-opaque, 1 late-opaque, 2 early-alpha-mask, 3 late-alpha-mask */
+int  trhost_pass_buffers(uint32_t slot, trhost_pass_buffers_t* out);
+int  trhost_instance_buffer(void** buffer);
+void* trhost_device(void);     /* the trhip_device in use                                           */
+
+int  trhost_render_graph_stats(uint32_t* num_heaps, uint64_t* bytes_reserved, uint64_t* bytes_used, uint32_t* num_passes);
+int  trhost_renderer_times(const char* renderer_name, float* cpu_ms, float* gpu_ms);
+
+/* Test hook (no GPU): drives RenderGraph::Heap's free-list allocator (RenderGraph.cpp:443-580).
+ * ops[i] > 0: Allocate(ops[i]) -> results[i] = offset (UINT64_MAX = no fit);
+ * ops[i] < 0: Free(results[-ops[i]-1]). */
+int  trhost_heap_sim(uint64_t heap_size, const int64_t* ops, uint32_t num_ops, uint64_t* results, uint64_t* used, uint64_t* peak, uint32_t* num_blocks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRHOST_H_ */

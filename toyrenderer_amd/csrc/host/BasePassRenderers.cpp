@@ -1,0 +1,513 @@
+// BasePassRenderers.cpp -- the renderers of the GPU-driven visibility path re-authored against the
+// RenderGraph / IRenderer / Graphic::AddComputePass API over the HIP back end.
+//
+// Reference: source/BasePassRenderers.cpp (UpdateInstanceConstsRenderer :18-165, BasePassRenderer
+// :167-589, GBufferRenderer :591-722).  Same pass structure, same transient buffers, same constants,
+// same dispatch order.  Differences, all forced by "compute only, no rasteriser":
+//   * RenderInstances (:406-503) sets a meshlet PSO and calls dispatchMeshIndirect; here the
+//     amplification shader's cull half runs as the compute shader "basepass_AS_Main LATE_CULL=N"
+//     dispatched INDIRECTLY on the same MeshletDispatchArgumentsBuffer, and its per-group
+//     DispatchMesh payload becomes three buffers (visibility mask per group, ordered visible list,
+//     draw arguments).  Mesh / pixel shading is out of scope.
+//   * the reference reuses ONE amplification / argument buffer for its four cull passes because the
+//     rasteriser consumes each result immediately; the results are the product here, so every pass
+//     slot (early/late x opaque/alpha-mask) owns its buffers.
+//   * the depth buffer GenerateHZB reads is copied from Scene::m_SyntheticDepth (stand-in for the
+//     rasteriser's output).
+#include <string>
+
+#include "CommonResources.h"
+#include "FFXHelpers.h"
+#include "Graphic.h"
+#include "GraphicConstants.h"
+#include "RenderGraph.h"
+#include "Scene.h"
+#include "VisibilityOutputs.h"
+#include "../ShaderInterop.h"
+
+using namespace interop;
+
+RenderGraph::ResourceHandle g_DepthStencilBufferRDGTextureHandle;            // BasePassRenderers.cpp:15
+
+// ---------------------------------------------------------------------------------------------------
+class UpdateInstanceConstsRenderer : public IRenderer
+{
+public:
+    UpdateInstanceConstsRenderer() : IRenderer{ "UpdateInstanceConstsRenderer" } {}
+
+    bool Setup(RenderGraph&) override
+    {
+        // :115-123 (returns false without primitives); static scenes skip the pass as well
+        return g_Scene->m_NumPrimitives != 0 && g_Scene->m_bUpdateInstanceTransforms;
+    }
+
+    void Render(nvrhi::CommandListHandle commandList, const RenderGraph&) override
+    {
+        {
+            PROFILE_GPU_SCOPED(commandList, "Upload Node Transforms");         // :127-130
+            commandList->writeBuffer(g_Scene->m_NodeLocalTransformsBuffer, g_Scene->m_NodeLocalTransforms.data(), g_Scene->m_NodeLocalTransforms.size());
+        }
+        const uint32_t numPrimitives = g_Scene->m_NumPrimitives;
+        UpdateInstanceConstsPassConstants passConstants;
+        passConstants.m_NumInstances = numPrimitives;
+
+        nvrhi::BindingSetDesc bindingSetDesc;                                 // :137-145 (u1 = TLAS descriptors: ray tracing, out of scope)
+        bindingSetDesc.bindings = {
+            nvrhi::BindingSetItem::PushConstants(0, sizeof(passConstants)),
+            nvrhi::BindingSetItem::StructuredBuffer_SRV(0, g_Scene->m_NodeLocalTransformsBuffer),
+            nvrhi::BindingSetItem::StructuredBuffer_SRV(1, g_Scene->m_PrimitiveIDToNodeIDBuffer),
+            nvrhi::BindingSetItem::StructuredBuffer_UAV(0, g_Scene->m_InstanceConstsBuffer),
+        };
+        Graphic::ComputePassParams computePassParams;                         // :147-155
+        computePassParams.m_CommandList = commandList;
+        computePassParams.m_ShaderName = "updateinstanceconsts_CS_UpdateInstanceConstsAndBuildTLAS";
+        computePassParams.m_BindingSetDesc = bindingSetDesc;
+        computePassParams.m_DispatchGroupSize = ComputeShaderUtils::GetGroupCount(passConstants.m_NumInstances, kNumThreadsPerWave);
+        computePassParams.m_PushConstantsData = &passConstants;
+        computePassParams.m_PushConstantsBytes = sizeof(passConstants);
+        g_Graphic.AddComputePass(computePassParams);
+    }
+};
+DEFINE_RENDERER(UpdateInstanceConstsRenderer);
+
+// ---------------------------------------------------------------------------------------------------
+class BasePassRenderer : public IRenderer
+{
+public:
+    enum PassSlot { kEarlyOpaque = 0, kLateOpaque, kEarlyAlphaMask, kLateAlphaMask, kNumPassSlots };
+
+    // results of the last recorded frame, for whoever consumes the visibility (rasteriser, gather, tests)
+    struct PassOutputs
+    {
+        bool m_bRan = false;
+        nvrhi::BufferHandle m_MeshletAmplificationDataBuffer, m_MeshletDispatchArgumentsBuffer;
+        nvrhi::BufferHandle m_MeshletVisibilityMaskBuffer, m_VisibleMeshletListBuffer, m_VisibleMeshletDrawArgsBuffer;
+    };
+    PassOutputs m_Outputs[kNumPassSlots];
+    nvrhi::BufferHandle m_LastLateCullInstanceCountBuffer, m_LastLateCullDispatchIndirectArgsBuffer;
+
+protected:
+    RenderGraph::ResourceHandle m_LateCullDispatchIndirectArgsRDGBufferHandle;
+    RenderGraph::ResourceHandle m_LateCullInstanceCountBufferRDGBufferHandle;
+    RenderGraph::ResourceHandle m_LateCullInstanceIDsBufferRDGBufferHandle;
+
+    FFXHelpers::SPD m_SPDHelper;
+
+    RenderGraph::ResourceHandle m_MeshletAmplificationDataBufferRDGBufferHandle[kNumPassSlots];
+    RenderGraph::ResourceHandle m_MeshletDispatchArgumentsBufferRDGBufferHandle[kNumPassSlots];
+    RenderGraph::ResourceHandle m_MeshletVisibilityMaskBufferRDGBufferHandle[kNumPassSlots];
+    RenderGraph::ResourceHandle m_VisibleMeshletListBufferRDGBufferHandle[kNumPassSlots];
+    RenderGraph::ResourceHandle m_VisibleMeshletDrawArgsBufferRDGBufferHandle[kNumPassSlots];
+
+    bool m_DoFrustumCulling = true;
+    bool m_bDoOcclusionCulling = true;
+    bool m_bDoMeshletConeCulling = true;
+    uint32_t m_CullingFlags = 0;
+    Vector2U m_HZBDimensions = Vector2U{ 1, 1 };
+    Vector4 m_CullingFrustum = Vector4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    uint32_t m_NumSlotsThisFrame = 0;
+
+public:
+    struct RenderBasePassParams
+    {
+        nvrhi::TextureHandle m_DepthBuffer;        // the reference carries a FramebufferDesc (:195); only its depth attachment matters here
+    };
+
+    BasePassRenderer(const char* rendererName) : IRenderer(rendererName) {}
+
+    bool Setup(RenderGraph& renderGraph) override
+    {
+        const uint32_t nbInstances = g_Scene->m_NumPrimitives;                // :225-229
+        if (nbInstances == 0) return true;
+
+        m_DoFrustumCulling = g_Scene->m_bEnableFrustumCulling;                // :231-233
+        m_bDoOcclusionCulling = g_Scene->m_bEnableOcclusionCulling;
+        m_bDoMeshletConeCulling = g_Scene->m_bEnableMeshletConeCulling;
+
+        const uint32_t maxGroups = g_Graphic.m_MaxMeshletGroups;              // kMaxThreadGroupsPerDimension in the reference (:237)
+        m_NumSlotsThisFrame = g_Scene->m_AlphaMaskPrimitiveIDs.empty() ? 2u : (uint32_t)kNumPassSlots;
+        for (uint32_t slot = 0; slot < m_NumSlotsThisFrame; ++slot) {
+            {
+                nvrhi::BufferDesc desc;                                       // :235-243
+                desc.byteSize = sizeof(MeshletAmplificationData) * (uint64_t)maxGroups;
+                desc.structStride = sizeof(MeshletAmplificationData);
+                desc.canHaveUAVs = true;
+                desc.initialState = nvrhi::ResourceStates::ShaderResource;
+                desc.debugName = "MeshletAmplificationDataBuffer";
+                renderGraph.CreateTransientResource(m_MeshletAmplificationDataBufferRDGBufferHandle[slot], desc);
+            }
+            {
+                nvrhi::BufferDesc desc;                                       // :245-254 (+ 4th word: valid records, ShaderInterop.h DispatchIndirectArgumentsEx)
+                desc.byteSize = sizeof(DispatchIndirectArgumentsEx);
+                desc.structStride = sizeof(DispatchIndirectArgumentsEx);
+                desc.canHaveUAVs = true;
+                desc.isDrawIndirectArgs = true;
+                desc.initialState = nvrhi::ResourceStates::IndirectArgument;
+                desc.debugName = "MeshletDispatchArgumentsBuffer";
+                renderGraph.CreateTransientResource(m_MeshletDispatchArgumentsBufferRDGBufferHandle[slot], desc);
+            }
+            {
+                nvrhi::BufferDesc desc;                                       // replaces MeshletPayload (ShaderInterop.h:200-205)
+                desc.byteSize = sizeof(uint32_t) * (uint64_t)maxGroups;
+                desc.structStride = sizeof(uint32_t);
+                desc.canHaveUAVs = true;
+                desc.initialState = nvrhi::ResourceStates::ShaderResource;
+                desc.debugName = "MeshletVisibilityMaskBuffer";
+                renderGraph.CreateTransientResource(m_MeshletVisibilityMaskBufferRDGBufferHandle[slot], desc);
+                desc.byteSize = sizeof(uint32_t) * (uint64_t)maxGroups * kNumThreadsPerWave;
+                desc.debugName = "VisibleMeshletListBuffer";
+                renderGraph.CreateTransientResource(m_VisibleMeshletListBufferRDGBufferHandle[slot], desc);
+            }
+            {
+                nvrhi::BufferDesc desc;                                       // replaces DispatchMesh(numVisible,1,1) (basepass.hlsl:120-121)
+                desc.byteSize = sizeof(DispatchIndirectArguments);
+                desc.structStride = sizeof(DispatchIndirectArguments);
+                desc.canHaveUAVs = true;
+                desc.isDrawIndirectArgs = true;
+                desc.initialState = nvrhi::ResourceStates::IndirectArgument;
+                desc.debugName = "VisibleMeshletDrawArgsBuffer";
+                renderGraph.CreateTransientResource(m_VisibleMeshletDrawArgsBufferRDGBufferHandle[slot], desc);
+            }
+        }
+
+        if (m_bDoOcclusionCulling) {                                          // :256-293
+            m_SPDHelper.CreateTransientResources(renderGraph);
+            {
+                nvrhi::BufferDesc desc;
+                desc.byteSize = sizeof(DispatchIndirectArguments);
+                desc.structStride = sizeof(DispatchIndirectArguments);
+                desc.canHaveUAVs = true;
+                desc.isDrawIndirectArgs = true;
+                desc.initialState = nvrhi::ResourceStates::IndirectArgument;
+                desc.debugName = "LateCullDispatchIndirectArgs";
+                renderGraph.CreateTransientResource(m_LateCullDispatchIndirectArgsRDGBufferHandle, desc);
+            }
+            {
+                nvrhi::BufferDesc desc;
+                desc.byteSize = sizeof(uint32_t);
+                desc.structStride = sizeof(uint32_t);
+                desc.canHaveUAVs = true;
+                desc.initialState = nvrhi::ResourceStates::ShaderResource;
+                desc.debugName = "LateCullInstanceCountBuffer";
+                renderGraph.CreateTransientResource(m_LateCullInstanceCountBufferRDGBufferHandle, desc);
+            }
+            {
+                nvrhi::BufferDesc desc;
+                desc.byteSize = sizeof(uint32_t) * (uint64_t)nbInstances;
+                desc.structStride = sizeof(uint32_t);
+                desc.canHaveUAVs = true;
+                desc.initialState = nvrhi::ResourceStates::ShaderResource;
+                desc.debugName = "LateCullInstanceIDsBuffer";
+                renderGraph.CreateTransientResource(m_LateCullInstanceIDsBufferRDGBufferHandle, desc);
+            }
+        }
+        return true;
+    }
+
+    void GPUCulling(nvrhi::CommandListHandle commandList, const RenderGraph& renderGraph, PassSlot slot, bool bLateCull, bool bAlphaMaskPrimitives)
+    {
+        PROFILE_GPU_SCOPED(commandList, "GPU Culling");                       // :306
+
+        const uint32_t nbInstances = (uint32_t)(bAlphaMaskPrimitives ? g_Scene->m_AlphaMaskPrimitiveIDs.size() : g_Scene->m_OpaquePrimitiveIDs.size());
+        if (nbInstances == 0) return;                                         // :310-314
+
+        nvrhi::BufferHandle meshletAmplificationDataBuffer = renderGraph.GetBuffer(m_MeshletAmplificationDataBufferRDGBufferHandle[slot]);
+        nvrhi::BufferHandle meshletDispatchArgumentsBuffer = renderGraph.GetBuffer(m_MeshletDispatchArgumentsBufferRDGBufferHandle[slot]);
+        nvrhi::BufferHandle lateCullDispatchIndirectArgsBuffer = m_bDoOcclusionCulling ? renderGraph.GetBuffer(m_LateCullDispatchIndirectArgsRDGBufferHandle) : g_CommonResources.DummyUIntStructuredBuffer;
+        nvrhi::BufferHandle lateCullInstanceCountBuffer = m_bDoOcclusionCulling ? renderGraph.GetBuffer(m_LateCullInstanceCountBufferRDGBufferHandle) : g_CommonResources.DummyUIntStructuredBuffer;
+        nvrhi::BufferHandle lateCullInstanceIDsBuffer = m_bDoOcclusionCulling ? renderGraph.GetBuffer(m_LateCullInstanceIDsBufferRDGBufferHandle) : g_CommonResources.DummyUIntStructuredBuffer;
+
+        {
+            PROFILE_GPU_SCOPED(commandList, "Clear Buffers");                  // :322-332
+            commandList->clearBufferUInt(meshletDispatchArgumentsBuffer, 0);
+            if (!bLateCull && m_bDoOcclusionCulling) {
+                commandList->clearBufferUInt(lateCullInstanceCountBuffer, 0);
+                commandList->clearBufferUInt(lateCullInstanceIDsBuffer, 0);
+            }
+        }
+
+        const uint32_t forcedMeshLOD = (g_Scene->m_ForceMeshLOD >= 0) ? (uint32_t)g_Scene->m_ForceMeshLOD : kInvalidMeshLOD;   // :334
+
+        GPUCullingPassConstants passParameters{};                             // :336-347
+        passParameters.m_NbInstances = nbInstances;
+        passParameters.m_CullingFlags = m_CullingFlags;
+        passParameters.m_Frustum = m_CullingFrustum;
+        passParameters.m_HZBDimensions = m_HZBDimensions;
+        passParameters.m_WorldToView = g_Scene->m_View.m_CullingWorldToView;
+        passParameters.m_PrevWorldToView = g_Scene->m_View.m_CullingPrevWorldToView;
+        passParameters.m_NearPlane = g_Scene->m_View.m_ZNearP;
+        passParameters.m_P00 = g_Scene->m_View.m_ViewToClip.m[0][0];
+        passParameters.m_P11 = g_Scene->m_View.m_ViewToClip.m[1][1];
+        passParameters.m_ForcedMeshLOD = forcedMeshLOD;
+        passParameters.m_MeshLODTarget = (2.0f / g_Scene->m_View.m_ViewToClip.m[1][1]) * (1.0f / (float)g_Graphic.m_RenderResolution.y);
+
+        nvrhi::BufferHandle passConstantBuffer = g_Graphic.CreateConstantBuffer(commandList, passParameters);   // :349
+
+        nvrhi::BindingSetDesc bindingSetDesc;                                 // :351-362
+        bindingSetDesc.bindings = {
+            nvrhi::BindingSetItem::ConstantBuffer(0, passConstantBuffer),
+            nvrhi::BindingSetItem::StructuredBuffer_SRV(0, g_Scene->m_InstanceConstsBuffer),
+            nvrhi::BindingSetItem::StructuredBuffer_SRV(1, bAlphaMaskPrimitives ? g_Scene->m_AlphaMaskInstanceIDsBuffer : g_Scene->m_OpaqueInstanceIDsBuffer),
+            nvrhi::BindingSetItem::StructuredBuffer_SRV(2, g_Graphic.m_GlobalMeshDataBuffer),
+            nvrhi::BindingSetItem::Texture_SRV(3, m_bDoOcclusionCulling ? g_Scene->m_HZB : g_CommonResources.BlackTexture),
+            nvrhi::BindingSetItem::StructuredBuffer_UAV(0, meshletAmplificationDataBuffer),
+            nvrhi::BindingSetItem::StructuredBuffer_UAV(1, meshletDispatchArgumentsBuffer),
+            nvrhi::BindingSetItem::StructuredBuffer_UAV(2, lateCullInstanceCountBuffer),
+            nvrhi::BindingSetItem::StructuredBuffer_UAV(3, lateCullInstanceIDsBuffer),
+            nvrhi::BindingSetItem::Sampler(0, g_CommonResources.LinearClampMinReductionSampler)
+        };
+
+        const std::string shaderName = "gpuculling_CS_GPUCulling LATE_CULL=" + std::to_string(bLateCull ? 1 : 0);   // :364
+
+        if (!bLateCull) {
+            Graphic::ComputePassParams computePassParams;                     // :367-375
+            computePassParams.m_CommandList = commandList;
+            computePassParams.m_ShaderName = shaderName;
+            computePassParams.m_BindingSetDesc = bindingSetDesc;
+            computePassParams.m_DispatchGroupSize = ComputeShaderUtils::GetGroupCount(nbInstances, kNumThreadsPerWave);
+            g_Graphic.AddComputePass(computePassParams);
+
+            if (m_bDoOcclusionCulling) {                                      // :377-389
+                bindingSetDesc.bindings = {
+                    nvrhi::BindingSetItem::StructuredBuffer_SRV(0, lateCullInstanceCountBuffer),
+                    nvrhi::BindingSetItem::StructuredBuffer_UAV(0, lateCullDispatchIndirectArgsBuffer)
+                };
+                computePassParams.m_ShaderName = "gpuculling_CS_BuildLateCullIndirectArgs";
+                computePassParams.m_BindingSetDesc = bindingSetDesc;
+                computePassParams.m_DispatchGroupSize = Vector3U{ 1, 1, 1 };
+                g_Graphic.AddComputePass(computePassParams);
+            }
+        } else if (m_bDoOcclusionCulling) {                                   // :392-402
+            Graphic::ComputePassParams computePassParams;
+            computePassParams.m_CommandList = commandList;
+            computePassParams.m_ShaderName = shaderName;
+            computePassParams.m_BindingSetDesc = bindingSetDesc;
+            computePassParams.m_IndirectArgsBuffer = lateCullDispatchIndirectArgsBuffer;
+            g_Graphic.AddComputePass(computePassParams);
+        }
+        m_LastLateCullInstanceCountBuffer = lateCullInstanceCountBuffer;
+        m_LastLateCullDispatchIndirectArgsBuffer = lateCullDispatchIndirectArgsBuffer;
+    }
+
+    void RenderInstances(nvrhi::CommandListHandle commandList, const RenderGraph& renderGraph, PassSlot slot, bool bIsLateCull, bool bAlphaMaskPrimitives)
+    {
+        PROFILE_GPU_SCOPED(commandList, "Render Instances");                  // :414
+
+        const uint32_t nbInstances = (uint32_t)(bAlphaMaskPrimitives ? g_Scene->m_AlphaMaskPrimitiveIDs.size() : g_Scene->m_OpaquePrimitiveIDs.size());
+        if (nbInstances == 0) return;                                         // :420-423
+        if (bIsLateCull && !m_bDoOcclusionCulling) return;
+
+        nvrhi::BufferHandle meshletAmplificationDataBuffer = renderGraph.GetBuffer(m_MeshletAmplificationDataBufferRDGBufferHandle[slot]);
+        nvrhi::BufferHandle meshletDispatchArgumentsBuffer = renderGraph.GetBuffer(m_MeshletDispatchArgumentsBufferRDGBufferHandle[slot]);
+        nvrhi::BufferHandle visMaskBuffer = renderGraph.GetBuffer(m_MeshletVisibilityMaskBufferRDGBufferHandle[slot]);
+        nvrhi::BufferHandle visibleListBuffer = renderGraph.GetBuffer(m_VisibleMeshletListBufferRDGBufferHandle[slot]);
+        nvrhi::BufferHandle visibleDrawArgsBuffer = renderGraph.GetBuffer(m_VisibleMeshletDrawArgsBufferRDGBufferHandle[slot]);
+
+        uint32_t finalCullingFlags = m_CullingFlags;
+        // assume alpha mask primitives are double-sided too, & ignore cone culling (:436-442, Q8)
+        if (bAlphaMaskPrimitives) finalCullingFlags &= ~kCullingFlagMeshletConeCullingEnable;
+
+        BasePassConstants basePassConstants{};                                // :445-458 (culling-relevant members)
+        basePassConstants.m_WorldToView = g_Scene->m_View.m_CullingWorldToView;
+        basePassConstants.m_Frustum = m_CullingFrustum;
+        basePassConstants.m_CullingFlags = finalCullingFlags;
+        basePassConstants.m_HZBDimensions = m_HZBDimensions;
+        basePassConstants.m_P00 = g_Scene->m_View.m_ViewToClip.m[0][0];
+        basePassConstants.m_P11 = g_Scene->m_View.m_ViewToClip.m[1][1];
+        basePassConstants.m_NearPlane = g_Scene->m_View.m_ZNearP;
+        basePassConstants.m_OutputResolution = g_Graphic.m_RenderResolution;
+
+        nvrhi::BufferHandle passConstantBuffer = g_Graphic.CreateConstantBuffer(commandList, basePassConstants);   // :460
+
+        nvrhi::BindingSetDesc bindingSetDesc;                                 // :463-479 (vertex / material / index SRVs t1,t3,t5,t6 feed MS/PS only)
+        bindingSetDesc.bindings = {
+            nvrhi::BindingSetItem::ConstantBuffer(0, passConstantBuffer),
+            nvrhi::BindingSetItem::StructuredBuffer_SRV(0, g_Scene->m_InstanceConstsBuffer),
+            nvrhi::BindingSetItem::StructuredBuffer_SRV(2, g_Graphic.m_GlobalMeshDataBuffer),
+            nvrhi::BindingSetItem::StructuredBuffer_SRV(4, g_Graphic.m_GlobalMeshletDataBuffer),
+            nvrhi::BindingSetItem::StructuredBuffer_SRV(7, meshletAmplificationDataBuffer),
+            nvrhi::BindingSetItem::Texture_SRV(8, m_bDoOcclusionCulling ? g_Scene->m_HZB : g_CommonResources.BlackTexture),
+            nvrhi::BindingSetItem::Sampler(4, g_CommonResources.LinearClampMinReductionSampler),
+            nvrhi::BindingSetItem::StructuredBuffer_UAV(0, visMaskBuffer),
+            nvrhi::BindingSetItem::StructuredBuffer_UAV(1, visibleListBuffer),
+            nvrhi::BindingSetItem::StructuredBuffer_UAV(2, visibleDrawArgsBuffer),
+        };
+
+        // :485-502: PSODesc.AS = "basepass_AS_Main LATE_CULL=%d"; dispatchMeshIndirect(0) on meshletDispatchArgumentsBuffer
+        Graphic::ComputePassParams computePassParams;
+        computePassParams.m_CommandList = commandList;
+        computePassParams.m_ShaderName = "basepass_AS_Main LATE_CULL=" + std::to_string(bIsLateCull ? 1 : 0);
+        computePassParams.m_BindingSetDesc = bindingSetDesc;
+        computePassParams.m_IndirectArgsBuffer = meshletDispatchArgumentsBuffer;
+        g_Graphic.AddComputePass(computePassParams);
+
+        PassOutputs& out = m_Outputs[slot];
+        out.m_bRan = true;
+        out.m_MeshletAmplificationDataBuffer = meshletAmplificationDataBuffer;
+        out.m_MeshletDispatchArgumentsBuffer = meshletDispatchArgumentsBuffer;
+        out.m_MeshletVisibilityMaskBuffer = visMaskBuffer;
+        out.m_VisibleMeshletListBuffer = visibleListBuffer;
+        out.m_VisibleMeshletDrawArgsBuffer = visibleDrawArgsBuffer;
+    }
+
+    void GenerateHZB(nvrhi::CommandListHandle commandList, const RenderGraph& renderGraph, const RenderBasePassParams& params)
+    {
+        if (g_Scene->m_bFreezeCullingCamera) return;                          // :507-510
+
+        PROFILE_GPU_SCOPED(commandList, "Generate HZB");                      // :513
+
+        MinMaxDownsampleConsts passParameters;                                // :515-517
+        passParameters.m_OutputDimensions = m_HZBDimensions;
+        passParameters.m_bDownsampleMax = !GraphicConstants::kInversedDepthBuffer;
+
+        nvrhi::TextureHandle depthStencilBuffer = params.m_DepthBuffer;       // :519
+
+        nvrhi::BindingSetDesc bindingSetDesc;                                 // :521-527
+        bindingSetDesc.bindings = {
+            nvrhi::BindingSetItem::PushConstants(0, sizeof(passParameters)),
+            nvrhi::BindingSetItem::Texture_SRV(0, depthStencilBuffer),
+            nvrhi::BindingSetItem::Texture_UAV(0, g_Scene->m_HZB),
+            nvrhi::BindingSetItem::Sampler(0, g_CommonResources.PointClampSampler)
+        };
+
+        Graphic::ComputePassParams computePassParams;                         // :529-537
+        computePassParams.m_CommandList = commandList;
+        computePassParams.m_ShaderName = "minmaxdownsample_CS_Main";
+        computePassParams.m_BindingSetDesc = bindingSetDesc;
+        computePassParams.m_DispatchGroupSize = ComputeShaderUtils::GetGroupCount(m_HZBDimensions, 8);
+        computePassParams.m_PushConstantsData = &passParameters;
+        computePassParams.m_PushConstantsBytes = sizeof(passParameters);
+        g_Graphic.AddComputePass(computePassParams);
+
+        // generate HZB mip chain (:539-541)
+        const nvrhi::SamplerReductionType reductionType = GraphicConstants::kInversedDepthBuffer ? nvrhi::SamplerReductionType::Minimum : nvrhi::SamplerReductionType::Maximum;
+        m_SPDHelper.Execute(commandList, renderGraph, depthStencilBuffer, g_Scene->m_HZB, reductionType);
+    }
+
+    void RenderBasePass(nvrhi::CommandListHandle commandList, const RenderGraph& renderGraph, const RenderBasePassParams& params)
+    {
+        for (PassOutputs& o : m_Outputs) o = PassOutputs{};
+
+        m_CullingFlags = m_DoFrustumCulling ? kCullingFlagFrustumCullingEnable : 0;                 // :551-553
+        m_CullingFlags |= m_bDoOcclusionCulling ? kCullingFlagOcclusionCullingEnable : 0;
+        m_CullingFlags |= m_bDoMeshletConeCulling ? kCullingFlagMeshletConeCullingEnable : 0;
+
+        m_HZBDimensions = m_bDoOcclusionCulling ? Vector2U{ g_Scene->m_HZB->getDesc().width, g_Scene->m_HZB->getDesc().height } : Vector2U{ 1, 1 };   // :555
+
+        Matrix projectionT = Transpose(g_Scene->m_View.m_ViewToClip);                               // :557-563
+        Vector4 frustumX = Vector4{ projectionT.m[3][0] + projectionT.m[0][0], projectionT.m[3][1] + projectionT.m[0][1], projectionT.m[3][2] + projectionT.m[0][2], projectionT.m[3][3] + projectionT.m[0][3] };
+        Vector4 frustumY = Vector4{ projectionT.m[3][0] + projectionT.m[1][0], projectionT.m[3][1] + projectionT.m[1][1], projectionT.m[3][2] + projectionT.m[1][2], projectionT.m[3][3] + projectionT.m[1][3] };
+        frustumX = Normalize(frustumX);
+        frustumY = Normalize(frustumY);
+        m_CullingFrustum = Vector4{ frustumX.x, frustumX.z, frustumY.y, frustumY.z };
+
+        GPUCulling(commandList, renderGraph, kEarlyOpaque, false /* bLateCull */, false /* bAlphaMaskPrimitives */);          // :565-566
+        RenderInstances(commandList, renderGraph, kEarlyOpaque, false, false);
+
+        if (m_bDoOcclusionCulling) {                                                                 // :568-581
+            // stand-in for the rasteriser: the frame's depth image arrives here
+            if (g_Scene->m_SyntheticDepth) commandList->copyTexture(params.m_DepthBuffer, g_Scene->m_SyntheticDepth);
+            GenerateHZB(commandList, renderGraph, params);
+
+            GPUCulling(commandList, renderGraph, kLateOpaque, true, false);
+            RenderInstances(commandList, renderGraph, kLateOpaque, true, false);
+
+            if (m_NumSlotsThisFrame == kNumPassSlots) {
+                GPUCulling(commandList, renderGraph, kEarlyAlphaMask, false, true);
+                RenderInstances(commandList, renderGraph, kEarlyAlphaMask, false, true);
+                GPUCulling(commandList, renderGraph, kLateAlphaMask, true, true);
+                RenderInstances(commandList, renderGraph, kLateAlphaMask, true, true);
+            }
+            GenerateHZB(commandList, renderGraph, params);
+        } else if (m_NumSlotsThisFrame == kNumPassSlots) {
+            // cull & render for alpha mask primitives, but no occlusion culling (:583-587)
+            GPUCulling(commandList, renderGraph, kEarlyAlphaMask, false, true);
+            RenderInstances(commandList, renderGraph, kEarlyAlphaMask, false, true);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+class GBufferRenderer : public BasePassRenderer
+{
+public:
+    GBufferRenderer() : BasePassRenderer("GBufferRenderer") {}
+
+    void Initialize() override
+    {
+        nvrhi::TextureDesc desc;                                              // :600-610
+        desc.width = GetNextPow2(g_Graphic.m_RenderResolution.x) >> 1;
+        desc.height = GetNextPow2(g_Graphic.m_RenderResolution.y) >> 1;
+        desc.format = GraphicConstants::kHZBFormat;
+        desc.isUAV = true;
+        desc.debugName = "HZB";
+        desc.mipLevels = ComputeNbMips(desc.width, desc.height);
+        desc.useClearValue = false;
+        desc.initialState = nvrhi::ResourceStates::ShaderResource;
+        g_Scene->m_HZB = g_Graphic.m_NVRHIDevice->createTexture(desc);
+
+        nvrhi::TextureDesc depth;                                             // stand-in for the rasteriser's depth output
+        depth.width = g_Graphic.m_RenderResolution.x;
+        depth.height = g_Graphic.m_RenderResolution.y;
+        depth.format = GraphicConstants::kDepthStencilFormat;
+        depth.debugName = "Synthetic Depth Source";
+        g_Scene->m_SyntheticDepth = g_Graphic.m_NVRHIDevice->createTexture(depth);
+
+        nvrhi::CommandListHandle commandList = g_Graphic.AllocateCommandList();   // :612-615
+        SCOPED_COMMAND_LIST_AUTO_QUEUE(commandList, "GBufferRenderer::Initialize");
+        commandList->clearTextureFloat(g_Scene->m_HZB, nvrhi::AllSubresources, nvrhi::Color{ GraphicConstants::kFarDepth });
+        commandList->clearTextureFloat(g_Scene->m_SyntheticDepth, nvrhi::AllSubresources, nvrhi::Color{ GraphicConstants::kFarDepth });
+    }
+
+    bool Setup(RenderGraph& renderGraph) override
+    {
+        BasePassRenderer::Setup(renderGraph);                                 // :620
+        {
+            nvrhi::TextureDesc desc;                                          // :646-655 (G-buffer colour targets :622-644 are pixel work, out of scope)
+            desc.width = g_Graphic.m_RenderResolution.x;
+            desc.height = g_Graphic.m_RenderResolution.y;
+            desc.format = GraphicConstants::kDepthStencilFormat;
+            desc.debugName = "Depth Buffer";
+            desc.isRenderTarget = true;
+            desc.setClearValue(nvrhi::Color{ GraphicConstants::kFarDepth });
+            desc.initialState = nvrhi::ResourceStates::DepthRead;
+            renderGraph.CreateTransientResource(g_DepthStencilBufferRDGTextureHandle, desc);
+        }
+        return true;
+    }
+
+    void Render(nvrhi::CommandListHandle commandList, const RenderGraph& renderGraph) override
+    {
+        if (g_Scene->m_NumPrimitives == 0) return;                            // :668-671
+        nvrhi::TextureHandle depthStencilBuffer = renderGraph.GetTexture(g_DepthStencilBufferRDGTextureHandle);
+        RenderBasePassParams params;                                          // :691-695
+        params.m_DepthBuffer = depthStencilBuffer;
+        RenderBasePass(commandList, renderGraph, params);
+    }
+};
+DEFINE_RENDERER(GBufferRenderer);
+
+// accessor for consumers of the visibility results (the reference has none: nothing reads them back)
+bool GetVisibilityPassBuffers(uint32_t slot, VisibilityPassBuffers* out)
+{
+    GBufferRenderer* r = static_cast<GBufferRenderer*>(g_GBufferRenderer);
+    if (slot >= BasePassRenderer::kNumPassSlots || !out) return false;
+    const BasePassRenderer::PassOutputs& o = r->m_Outputs[slot];
+    out->m_bRan = o.m_bRan;
+    out->m_MeshletAmplificationDataBuffer = o.m_MeshletAmplificationDataBuffer;
+    out->m_MeshletDispatchArgumentsBuffer = o.m_MeshletDispatchArgumentsBuffer;
+    out->m_MeshletVisibilityMaskBuffer = o.m_MeshletVisibilityMaskBuffer;
+    out->m_VisibleMeshletListBuffer = o.m_VisibleMeshletListBuffer;
+    out->m_VisibleMeshletDrawArgsBuffer = o.m_VisibleMeshletDrawArgsBuffer;
+    out->m_LateCullInstanceCountBuffer = r->m_LastLateCullInstanceCountBuffer;
+    out->m_LateCullDispatchIndirectArgsBuffer = r->m_LastLateCullDispatchIndirectArgsBuffer;
+    return true;
+}
+
+void ReleaseVisibilityPassBuffers()
+{
+    GBufferRenderer* r = static_cast<GBufferRenderer*>(g_GBufferRenderer);
+    for (auto& o : r->m_Outputs) o = BasePassRenderer::PassOutputs{};
+    r->m_LastLateCullInstanceCountBuffer = nullptr;
+    r->m_LastLateCullDispatchIndirectArgsBuffer = nullptr;
+}

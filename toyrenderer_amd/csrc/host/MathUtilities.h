@@ -1,0 +1,47 @@
+// MathUtilities.h -- the few math helpers of the reference the path uses
+// (source/MathUtilities.h:47-67, source/MathUtilities.cpp:3-38, SimpleMath wrappers).
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+
+#include "../ShaderInterop.h"
+
+using interop::Matrix;
+using interop::Vector2U;
+using interop::Vector3U;
+using interop::Vector4;
+
+// MathUtilities.h:47-61
+constexpr uint32_t GetNextPow2(uint32_t x)
+{
+    if (x == 0) return 1;
+    --x;
+    x |= x >> 1; x |= x >> 2; x |= x >> 4; x |= x >> 8; x |= x >> 16;
+    return x + 1;
+}
+
+// MathUtilities.h:64-67
+constexpr uint32_t DivideAndRoundUp(uint32_t dividend, uint32_t divisor) { return (dividend + divisor - 1) / divisor; }
+
+inline Matrix Transpose(const Matrix& m)
+{
+    Matrix t;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) t.m[i][j] = m.m[j][i];
+    return t;
+}
+
+// Vector4::Normalize (SimpleMath.inl:1129-1135 -> XMVector4Normalize).  DirectXMath is absent; the
+// build's convention is v / sqrt(dot4) with the dot product as an FMA chain (DESIGN.md "Arithmetic").
+inline Vector4 Normalize(const Vector4& v)
+{
+    const float d = std::fmaf(v.w, v.w, std::fmaf(v.z, v.z, std::fmaf(v.y, v.y, v.x * v.x)));
+    const float l = std::sqrt(d);
+    return Vector4{ v.x / l, v.y / l, v.z / l, v.w / l };
+}
+
+// MathUtilities.cpp:3-38
+void ModifyPerspectiveMatrix(Matrix& mat, float nearPlane, float farPlane, bool bReverseZ, bool bInfiniteZ);
+// XMMatrixPerspectiveFovRH (SimpleMath.inl:2193-2199)
+Matrix CreatePerspectiveFieldOfView(float fovY, float aspect, float nearPlane, float farPlane);

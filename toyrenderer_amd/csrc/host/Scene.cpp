@@ -1,0 +1,119 @@
+// Scene.cpp -- see Scene.h.  Cites are to the reference's source/Scene.cpp.
+#include "Scene.h"
+
+#include <cstring>
+
+#include "Graphic.h"
+#include "GraphicConstants.h"
+#include "../ShaderInterop.h"
+
+extern IRenderer* g_UpdateInstanceConstsRenderer;
+extern IRenderer* g_GBufferRenderer;
+
+void View::Update()
+{
+    // Scene.cpp:116-118: keep last frame's matrices
+    m_PrevWorldToView = m_WorldToView;
+    m_PrevViewToClip = m_ViewToClip;
+    if (m_bHasPending) m_WorldToView = m_PendingWorldToView;                  // :121-122 (camera from the application)
+
+    if (!m_bUseExplicitProjection) {                                          // :124-125
+        const float kKindaBigNumber = 1e10f;
+        m_ViewToClip = CreatePerspectiveFieldOfView(m_FOV, m_AspectRatio, m_ZNearP, kKindaBigNumber);
+        ModifyPerspectiveMatrix(m_ViewToClip, m_ZNearP, kKindaBigNumber, GraphicConstants::kInversedDepthBuffer, GraphicConstants::kInfiniteDepthBuffer);
+    }
+    // TAA jitter (:127-131) is out of scope (no TAA renderer)
+
+    if (!g_Scene->m_bFreezeCullingCamera) {                                   // :139-144
+        m_CullingPrevWorldToView = m_PrevWorldToView;
+        m_CullingWorldToView = m_WorldToView;
+    }
+}
+
+void Scene::Initialize()
+{
+    m_RenderGraph = std::make_shared<RenderGraph>();
+    m_RenderGraph->Initialize();
+    m_View.m_AspectRatio = (float)g_Graphic.m_RenderResolution.x / (float)g_Graphic.m_RenderResolution.y;
+}
+
+void Scene::LoadFromArrays(const void* instances, uint32_t numInstances, const void* meshData, uint32_t numMeshes,
+                           const void* meshlets, uint64_t numMeshlets, const uint32_t* opaqueIds, uint32_t numOpaque,
+                           const uint32_t* alphaMaskIds, uint32_t numAlphaMask)
+{
+    nvrhi::DeviceHandle device = g_Graphic.m_NVRHIDevice;
+    auto make = [&](const char* name, uint64_t bytes, uint32_t stride, bool uav) {
+        nvrhi::BufferDesc d;
+        d.byteSize = bytes ? bytes : stride;
+        d.structStride = stride;
+        d.debugName = name;
+        d.canHaveUAVs = uav;
+        d.initialState = nvrhi::ResourceStates::ShaderResource;
+        return device->createBuffer(d);
+    };
+    auto upload = [&](nvrhi::BufferHandle b, const void* src, uint64_t bytes) {
+        if (bytes) nvrhi::throwIfFailed(trhip_buffer_upload(b->native(), 0, src, bytes), "Scene upload");
+    };
+    m_NumPrimitives = numInstances;
+    // UpdateInstanceConstsRenderer::CreateInstanceConstsBuffer (BasePassRenderers.cpp:23-62)
+    m_InstanceConstsBuffer = make("Instance Consts Buffer", (uint64_t)numInstances * sizeof(interop::BasePassInstanceConstants), sizeof(interop::BasePassInstanceConstants), true);
+    upload(m_InstanceConstsBuffer, instances, (uint64_t)numInstances * sizeof(interop::BasePassInstanceConstants));
+    // UploadGlobalMeshBuffers (SceneLoading.cpp:1016-1088)
+    g_Graphic.m_GlobalMeshDataBuffer = make("GlobalMeshDataBuffer", (uint64_t)numMeshes * sizeof(interop::MeshData), sizeof(interop::MeshData), false);
+    upload(g_Graphic.m_GlobalMeshDataBuffer, meshData, (uint64_t)numMeshes * sizeof(interop::MeshData));
+    g_Graphic.m_GlobalMeshletDataBuffer = make("GlobalMeshletDataBuffer", numMeshlets * sizeof(interop::MeshletData), sizeof(interop::MeshletData), false);
+    upload(g_Graphic.m_GlobalMeshletDataBuffer, meshlets, numMeshlets * sizeof(interop::MeshletData));
+    // Scene::UpdateInstanceIDsBuffers (Scene.cpp:282-362)
+    m_OpaquePrimitiveIDs.assign(opaqueIds, opaqueIds + numOpaque);
+    m_AlphaMaskPrimitiveIDs.assign(alphaMaskIds, alphaMaskIds + numAlphaMask);
+    m_OpaqueInstanceIDsBuffer = make("OpaqueInstanceIDsBuffer", (uint64_t)numOpaque * 4, 4, false);
+    upload(m_OpaqueInstanceIDsBuffer, opaqueIds, (uint64_t)numOpaque * 4);
+    m_AlphaMaskInstanceIDsBuffer = make("AlphaMaskInstanceIDsBuffer", (uint64_t)numAlphaMask * 4, 4, false);
+    upload(m_AlphaMaskInstanceIDsBuffer, alphaMaskIds, (uint64_t)numAlphaMask * 4);
+}
+
+void Scene::LoadNodes(const void* nodes, uint32_t numNodes, const uint32_t* primitiveToNode)
+{
+    // UpdateInstanceConstsRenderer::CreateNodeTransformsBuffer (BasePassRenderers.cpp:64-104)
+    nvrhi::DeviceHandle device = g_Graphic.m_NVRHIDevice;
+    m_NumNodes = numNodes;
+    m_NodeLocalTransforms.assign((const uint8_t*)nodes, (const uint8_t*)nodes + (size_t)numNodes * sizeof(interop::NodeLocalTransform));
+    nvrhi::BufferDesc d;
+    d.byteSize = (uint64_t)numNodes * sizeof(interop::NodeLocalTransform);
+    d.structStride = sizeof(interop::NodeLocalTransform);
+    d.debugName = "Node Transforms Buffer";
+    m_NodeLocalTransformsBuffer = device->createBuffer(d);
+    nvrhi::BufferDesc p;
+    p.byteSize = (uint64_t)m_NumPrimitives * 4;
+    p.structStride = 4;
+    p.debugName = "PrimitiveIDToNodeID Buffer";
+    m_PrimitiveIDToNodeIDBuffer = device->createBuffer(p);
+    nvrhi::throwIfFailed(trhip_buffer_upload(m_PrimitiveIDToNodeIDBuffer->native(), 0, primitiveToNode, p.byteSize), "Scene upload");
+    m_bUpdateInstanceTransforms = true;
+}
+
+void Scene::PostSceneLoad() {}
+
+void Scene::Update()
+{
+    m_View.Update();                                                          // Scene.cpp:475
+
+    tf::Taskflow tf;
+    m_RenderGraph->InitializeForFrame(tf);                                    // :487
+    // pass schedule (:491-512): only the passes of the visibility path exist here
+    m_RenderGraph->AddRenderer(g_UpdateInstanceConstsRenderer);
+    m_RenderGraph->AddRenderer(g_GBufferRenderer);
+    m_RenderGraph->Compile();                                                 // :515
+    m_Executor.corun(tf);                                                     // :518
+}
+
+void Scene::Shutdown()
+{
+    m_RenderGraph->Shutdown();
+    m_RenderGraph.reset();
+    m_InstanceConstsBuffer = nullptr;
+    m_OpaqueInstanceIDsBuffer = m_AlphaMaskInstanceIDsBuffer = nullptr;
+    m_NodeLocalTransformsBuffer = m_PrimitiveIDToNodeIDBuffer = nullptr;
+    m_HZB = nullptr;
+    m_SyntheticDepth = nullptr;
+}

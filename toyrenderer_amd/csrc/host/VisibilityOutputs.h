@@ -1,0 +1,21 @@
+// VisibilityOutputs.h -- where a consumer (software rasteriser, multi-GPU gather, tests) finds the
+// buffers the last recorded frame's cull passes wrote.  New in this build: in the reference the
+// mesh-shader stage consumes the amplification payload on chip and nothing is exposed.
+#pragma once
+
+#include "nvrhi_lite.h"
+
+struct VisibilityPassBuffers
+{
+    bool m_bRan = false;
+    nvrhi::BufferHandle m_MeshletAmplificationDataBuffer;   // MeshletAmplificationData[G]
+    nvrhi::BufferHandle m_MeshletDispatchArgumentsBuffer;   // {G,1,1, validRecords}
+    nvrhi::BufferHandle m_MeshletVisibilityMaskBuffer;      // uint32 per group: lane-visibility ballot
+    nvrhi::BufferHandle m_VisibleMeshletListBuffer;         // (g << 5) | lane, canonical order
+    nvrhi::BufferHandle m_VisibleMeshletDrawArgsBuffer;     // {numVisible,1,1}
+    nvrhi::BufferHandle m_LateCullInstanceCountBuffer, m_LateCullDispatchIndirectArgsBuffer;
+};
+
+// slot: 0 early-opaque, 1 late-opaque, 2 early-alpha-mask, 3 late-alpha-mask
+bool GetVisibilityPassBuffers(uint32_t slot, VisibilityPassBuffers* out);
+void ReleaseVisibilityPassBuffers();

@@ -530,6 +530,34 @@ int trhip_cmd_clear_texture_f32(trhip_cmdlist cl, trhip_texture tex, float value
     return TRHIP_OK;
 }
 
+int trhip_cmd_copy_buffer(trhip_cmdlist cl, trhip_buffer dst, uint64_t dstOff, trhip_buffer src, uint64_t srcOff, uint64_t bytes)
+{
+    TRHIP_RECORDING(cl);
+    if (!dst || !src) return fail(TRHIP_ERR_INVALID, "copy_buffer: null buffer");
+    if (!dst->ptr || !src->ptr) return fail(TRHIP_ERR_STATE, "copy_buffer: a buffer has no memory bound");
+    if (dstOff + bytes > dst->byteSize || srcOff + bytes > src->byteSize) return fail(TRHIP_ERR_INVALID, "copy_buffer(%s <- %s): range exceeds a buffer", dst->name.c_str(), src->name.c_str());
+    void* d = (char*)dst->ptr + dstOff;
+    const void* sp = (const char*)src->ptr + srcOff;
+    cl->hold(dst); cl->hold(src);
+    cl->ops.push_back({ "", [d, sp, bytes](hipStream_t s) { TRHIP_HIP(hipMemcpyAsync(d, sp, (size_t)bytes, hipMemcpyDeviceToDevice, s)); return (int)TRHIP_OK; } });
+    return TRHIP_OK;
+}
+
+int trhip_cmd_copy_texture(trhip_cmdlist cl, trhip_texture dst, trhip_texture src)
+{
+    TRHIP_RECORDING(cl);
+    if (!dst || !src) return fail(TRHIP_ERR_INVALID, "copy_texture: null texture");
+    if (!dst->ptr || !src->ptr) return fail(TRHIP_ERR_STATE, "copy_texture: a texture has no memory bound");
+    if (dst->width != src->width || dst->height != src->height || dst->mips != src->mips || dst->format != src->format)
+        return fail(TRHIP_ERR_INVALID, "copy_texture(%s <- %s): descriptions differ", dst->name.c_str(), src->name.c_str());
+    void* d = dst->ptr;
+    const void* sp = src->ptr;
+    const uint64_t bytes = src->totalBytes;
+    cl->hold(dst); cl->hold(src);
+    cl->ops.push_back({ "", [d, sp, bytes](hipStream_t s) { TRHIP_HIP(hipMemcpyAsync(d, sp, (size_t)bytes, hipMemcpyDeviceToDevice, s)); return (int)TRHIP_OK; } });
+    return TRHIP_OK;
+}
+
 static int recordDispatch(trhip_cmdlist cl, const char* name, const trhip_binding* b, uint32_t nb, const void* push, uint32_t pushBytes,
                           bool indirect, trhip_buffer args, uint32_t argsOff, uint32_t gx, uint32_t gy, uint32_t gz)
 {

@@ -1,0 +1,208 @@
+"""ctypes binding of the C++ host mirror (include/trhost.h -> lib/libtoyrenderer_host.so):
+Graphic / Scene / RenderGraph / BasePassRenderers driving the HIP kernels through the C ABI.
+This is the drop-in path; there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import interop as I
+from . import rhi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtoyrenderer_host.so")
+
+HOST_SYMBOLS = [
+    "trhost_last_error", "trhost_initialize", "trhost_shutdown", "trhost_load_scene", "trhost_load_nodes",
+    "trhost_set_node_transforms", "trhost_set_camera", "trhost_set_culling", "trhost_set_limits", "trhost_upload_depth",
+    "trhost_upload_hzb_mip", "trhost_download_hzb_mip", "trhost_hzb_info", "trhost_frame", "trhost_wait_idle",
+    "trhost_pass_buffers", "trhost_instance_buffer", "trhost_device", "trhost_render_graph_stats", "trhost_renderer_times",
+    "trhost_heap_sim",
+]
+
+
+class PassBuffers(C.Structure):
+    _fields_ = [("ran", C.c_int), ("records", C.c_void_p), ("dispatch_args", C.c_void_p), ("vis_mask", C.c_void_p),
+                ("visible_list", C.c_void_p), ("draw_args", C.c_void_p), ("late_count", C.c_void_p), ("late_args", C.c_void_p)]
+
+
+class HostError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    rhi.load()   # libtrhip.so first (RPATH $ORIGIN also finds it)
+    if not os.path.exists(LIB_PATH):
+        raise HostError(f"{LIB_PATH} is missing: run __graft_entry__.build()")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+    L.trhost_last_error.restype = C.c_char_p
+    L.trhost_initialize.argtypes = [C.c_int, u32, u32, vp]
+    L.trhost_shutdown.restype = None
+    L.trhost_load_scene.argtypes = [vp, u32, vp, u32, vp, u64, vp, u32, vp, u32]
+    L.trhost_load_nodes.argtypes = [vp, u32, vp]
+    L.trhost_set_node_transforms.argtypes = [vp, u32]
+    L.trhost_set_camera.argtypes = [vp, vp, vp, C.c_float]
+    L.trhost_set_culling.argtypes = [C.c_int] * 5
+    L.trhost_set_limits.argtypes = [u32, u64]
+    L.trhost_upload_depth.argtypes = [vp, u32, u32]
+    L.trhost_upload_hzb_mip.argtypes = [u32, vp, u64]
+    L.trhost_download_hzb_mip.argtypes = [u32, vp, u64]
+    L.trhost_hzb_info.argtypes = [C.POINTER(u32)] * 3
+    L.trhost_pass_buffers.argtypes = [u32, C.POINTER(PassBuffers)]
+    L.trhost_instance_buffer.argtypes = [C.POINTER(vp)]
+    L.trhost_device.restype = vp
+    L.trhost_render_graph_stats.argtypes = [C.POINTER(u32), C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
+    L.trhost_renderer_times.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.trhost_heap_sim.argtypes = [u64, vp, u32, vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise HostError(load().trhost_last_error().decode(errors="replace"))
+
+
+def heap_sim(heap_size: int, ops):
+    """RenderGraph::Heap allocator without a GPU (tests)."""
+    ops = np.asarray(ops, np.int64)
+    res = np.zeros(len(ops), np.uint64)
+    used, peak, nb = C.c_uint64(), C.c_uint64(), C.c_uint32()
+    _check(load().trhost_heap_sim(heap_size, ops.ctypes.data, len(ops), res.ctypes.data, C.byref(used), C.byref(peak), C.byref(nb)))
+    return res, int(used.value), int(peak.value), int(nb.value)
+
+
+def _download(handle, dtype, count):
+    out = np.empty(count, dtype)
+    if count:
+        rc = rhi.load().trhip_buffer_download(C.c_void_p(handle), 0, out.ctypes.data, out.nbytes)
+        if rc != 0:
+            raise HostError(rhi.load().trhip_last_error().decode())
+    return out
+
+
+class Renderer:
+    """One process-wide renderer context (Graphic / Scene are singletons in the reference)."""
+
+    def __init__(self, render=(3840, 2160), device_index=0, stream: int | None = None, max_groups: int | None = None,
+                 max_transient_bytes: int | None = None):
+        L = load()
+        _check(L.trhost_initialize(device_index, render[0], render[1], C.c_void_p(stream) if stream else None))
+        self.render = render
+        self.max_groups = 65535
+        if max_groups or max_transient_bytes:
+            _check(L.trhost_set_limits(max_groups or 0, max_transient_bytes or 0))
+            if max_groups:
+                self.max_groups = max_groups
+        w, h, m = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(L.trhost_hzb_info(C.byref(w), C.byref(h), C.byref(m)))
+        self.hzb_w, self.hzb_h, self.hzb_mips = w.value, h.value, m.value
+
+    def load_scene(self, instances, meshData, meshlets, opaqueIds, alphaMaskIds):
+        a = [np.ascontiguousarray(x) for x in (instances, meshData, meshlets)]
+        op = np.ascontiguousarray(opaqueIds, np.uint32)
+        am = np.ascontiguousarray(alphaMaskIds, np.uint32)
+        _check(load().trhost_load_scene(a[0].ctypes.data, len(a[0]), a[1].ctypes.data, len(a[1]), a[2].ctypes.data, len(a[2]),
+                                        op.ctypes.data if op.size else None, op.size, am.ctypes.data if am.size else None, am.size))
+        self.num_opaque, self.num_alpha = op.size, am.size
+
+    def load_nodes(self, nodes, prim_to_node):
+        n = np.ascontiguousarray(nodes); p = np.ascontiguousarray(prim_to_node, np.uint32)
+        _check(load().trhost_load_nodes(n.ctypes.data, len(n), p.ctypes.data))
+
+    def set_node_transforms(self, nodes):
+        n = np.ascontiguousarray(nodes)
+        _check(load().trhost_set_node_transforms(n.ctypes.data, len(n)))
+
+    def set_camera(self, view):
+        w = np.ascontiguousarray(view.worldToView, np.float32); p = np.ascontiguousarray(view.prevWorldToView, np.float32)
+        c = np.ascontiguousarray(view.viewToClip, np.float32)
+        _check(load().trhost_set_camera(w.ctypes.data, p.ctypes.data, c.ctypes.data, float(view.nearPlane)))
+
+    def set_culling(self, flags=7, freeze=False, force_mesh_lod=-1):
+        _check(load().trhost_set_culling(flags & 1, (flags >> 1) & 1, (flags >> 2) & 1, int(freeze), int(force_mesh_lod)))
+        self.flags = flags
+
+    def upload_depth(self, depth):
+        d = np.ascontiguousarray(depth, np.float32)
+        _check(load().trhost_upload_depth(d.ctypes.data, d.shape[1], d.shape[0]))
+
+    def upload_hzb(self, texels, offsets):
+        for k in range(self.hzb_mips):
+            mw, mh = max(self.hzb_w >> k, 1), max(self.hzb_h >> k, 1)
+            t = np.ascontiguousarray(texels[offsets[k]:offsets[k] + mw * mh], np.uint16)
+            _check(load().trhost_upload_hzb_mip(k, t.ctypes.data, t.nbytes))
+
+    def download_hzb(self) -> np.ndarray:
+        parts = []
+        for k in range(self.hzb_mips):
+            t = np.empty(max(self.hzb_w >> k, 1) * max(self.hzb_h >> k, 1), np.uint16)
+            _check(load().trhost_download_hzb_mip(k, t.ctypes.data, t.nbytes))
+            parts.append(t)
+        return np.concatenate(parts)
+
+    def frame(self):
+        _check(load().trhost_frame())
+
+    def wait_idle(self):
+        _check(load().trhost_wait_idle())
+
+    def pass_buffers(self, slot: int) -> PassBuffers:
+        pb = PassBuffers()
+        _check(load().trhost_pass_buffers(slot, C.byref(pb)))
+        return pb
+
+    def results(self):
+        """Read back every pass slot of the last frame (tests)."""
+        self.wait_idle()
+        out = {}
+        late = None
+        for s in range(4):
+            pb = self.pass_buffers(s)
+            if not pb.ran:
+                out[s] = None
+                continue
+            args = _download(pb.dispatch_args, np.uint32, 4)
+            G = int(min(args[0], args[3], self.max_groups))
+            draw = _download(pb.draw_args, np.uint32, 3)
+            V = int(min(draw[0], self.max_groups * 32))
+            out[s] = dict(dispatchArgs=args[:3].copy(), validRecords=int(args[3]),
+                          records=_download(pb.records, I.MeshletAmplificationData, G),
+                          visMask=_download(pb.vis_mask, np.uint32, G),
+                          visibleList=_download(pb.visible_list, np.uint32, V), drawArgs=draw)
+            late = pb
+        if late is not None and (self.flags & 2):
+            out["lateCount"] = int(_download(late.late_count, np.uint32, 1)[0])
+            out["lateArgs"] = _download(late.late_args, np.uint32, 3)
+        return out
+
+    def instances(self, count) -> np.ndarray:
+        h = C.c_void_p()
+        _check(load().trhost_instance_buffer(C.byref(h)))
+        self.wait_idle()
+        return _download(h.value, I.BasePassInstanceConstants, count)
+
+    def render_graph_stats(self):
+        nh, res, used, npass = C.c_uint32(), C.c_uint64(), C.c_uint64(), C.c_uint32()
+        _check(load().trhost_render_graph_stats(C.byref(nh), C.byref(res), C.byref(used), C.byref(npass)))
+        return dict(heaps=nh.value, reserved=res.value, used=used.value, passes=npass.value)
+
+    def renderer_times(self, name: str):
+        c, g = C.c_float(), C.c_float()
+        _check(load().trhost_renderer_times(name.encode(), C.byref(c), C.byref(g)))
+        return float(c.value), float(g.value)
+
+    def device(self) -> int:
+        return load().trhost_device()
+
+    def shutdown(self):
+        load().trhost_shutdown()

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "trhip_texture_release", "trhip_texture_device_ptr", "trhip_texture_mip_info", "trhip_texture_size",
     "trhip_buffer_upload", "trhip_buffer_download", "trhip_texture_upload", "trhip_texture_download",
     "trhip_cmd_create", "trhip_cmd_release", "trhip_cmd_open", "trhip_cmd_close", "trhip_cmd_write_buffer",
-    "trhip_cmd_clear_buffer_u32", "trhip_cmd_clear_texture_f32", "trhip_cmd_dispatch", "trhip_cmd_dispatch_indirect",
+    "trhip_cmd_clear_buffer_u32", "trhip_cmd_clear_texture_f32", "trhip_cmd_copy_buffer", "trhip_cmd_copy_texture", "trhip_cmd_dispatch", "trhip_cmd_dispatch_indirect",
     "trhip_cmd_begin_timer", "trhip_cmd_end_timer", "trhip_cmd_begin_marker", "trhip_cmd_end_marker",
     "trhip_queue_execute",
     "trhip_timer_create", "trhip_timer_release", "trhip_timer_get_ms",
@@ -118,6 +118,8 @@ def load() -> C.CDLL:
     L.trhip_cmd_write_buffer.argtypes = [vp, vp, u64, vp, u64]
     L.trhip_cmd_clear_buffer_u32.argtypes = [vp, vp, u32]
     L.trhip_cmd_clear_texture_f32.argtypes = [vp, vp, C.c_float]
+    L.trhip_cmd_copy_buffer.argtypes = [vp, vp, u64, vp, u64, u64]
+    L.trhip_cmd_copy_texture.argtypes = [vp, vp, vp]
     L.trhip_cmd_dispatch.argtypes = [vp, C.c_char_p, C.POINTER(Binding), u32, vp, u32, u32, u32, u32]
     L.trhip_cmd_dispatch_indirect.argtypes = [vp, C.c_char_p, C.POINTER(Binding), u32, vp, u32, vp, u32]
     L.trhip_cmd_begin_timer.argtypes = [vp, vp]
@@ -261,6 +263,12 @@ class CommandList:
 
     def clear_texture_f32(self, tex: Texture, value: float):
         _check(load().trhip_cmd_clear_texture_f32(self.h, tex.h, value))
+
+    def copy_buffer(self, dst: Buffer, src: Buffer, nbytes: int, dst_offset: int = 0, src_offset: int = 0):
+        _check(load().trhip_cmd_copy_buffer(self.h, dst.h, dst_offset, src.h, src_offset, nbytes))
+
+    def copy_texture(self, dst: Texture, src: Texture):
+        _check(load().trhip_cmd_copy_texture(self.h, dst.h, src.h))
 
     def constant_buffer(self, data: np.ndarray, name="cb") -> Buffer:
         """Graphic::CreateConstantBuffer (Graphic.h:66-72): volatile CB + writeBuffer."""
