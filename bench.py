@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 
 from toyrenderer_amd import interop as I  # noqa: E402
 from toyrenderer_amd import synth  # noqa: E402
+from toyrenderer_amd.gather import shard_range  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 DOMINANT = "basepass_AS_Main LATE_CULL=0#cull"
@@ -40,14 +41,10 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def shard_range(n: int, rank: int, world: int):
-    return (rank * n) // world, ((rank + 1) * n) // world
-
-
-def build_shard(spec: synth.SceneSpec, rank: int, world: int, dev, threads: int = 8):
-    """Upload this rank's shard: the full instance + mesh tables (replicated, ~230 MB), the id list of
-    the owned contiguous instance range, and ONLY the owned meshes' meshlets (co-sharded)."""
-    from toyrenderer_amd.frame import GpuScene
+def build_shard(spec: synth.SceneSpec, rank: int, world: int, renderer, threads: int = 8):
+    """Load this rank's shard through the host library: the full instance + mesh tables (replicated,
+    ~230 MB), the id list of the owned contiguous instance range, and ONLY the owned meshes' meshlets
+    (co-sharded), streamed in chunk by chunk."""
     assert spec.unique, "the sharded bench uses the unique-meshlet configs (C3/C4)"
     t0 = time.time()
     md, total = synth.gen_mesh_table(spec)
@@ -75,7 +72,7 @@ def build_shard(spec: synth.SceneSpec, rank: int, world: int, dev, threads: int 
     lods["m_MeshletDataBufferIdx"][owned] -= np.uint32(base)
     lods["m_NumMeshlets"][~owned] = 0
     ids = np.arange(i0, i1, dtype=np.uint32)
-    gs = GpuScene(dev, inst, md_local, None, ids, np.zeros(0, np.uint32), num_meshlets=max(n_local, 1))
+    renderer.load_scene(inst, md_local, None, ids, np.zeros(0, np.uint32), num_meshlets=max(n_local, 1))
 
     def gen(b):
         e = min(b + cm, spec.num_meshes)
@@ -84,10 +81,9 @@ def build_shard(spec: synth.SceneSpec, rank: int, world: int, dev, threads: int 
         for off, chunk in ex.map(gen, range(c0, c1, cm)):
             lo, hi = max(off, base), min(off + len(chunk), end)
             if hi > lo:
-                gs.meshlets.upload(chunk[lo - off:hi - off], offset=(lo - base) * 32)
-    tested_upper = int(md["m_MeshLODDatas"]["m_NumMeshlets"][i0:i1, 0].sum())
+                renderer.upload_meshlets(lo - base, chunk[lo - off:hi - off])
     log(f"[rank {rank}] shard: instances [{i0},{i1}) meshlets {n_local} ({n_local * 32 / 1e9:.2f} GB) in {time.time() - t0:.1f}s")
-    return gs, (i0, i1), n_local, total, tested_upper
+    return (i0, i1), n_local, total
 
 
 def cpu_baseline(spec: synth.SceneSpec, view, depth, sample_instances: int, threads: int):
@@ -140,34 +136,41 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_gather = bool(os.environ.get("TR_FORCE_GATHER"))     # exercise the RCCL path with a 1-rank group (tests)
+    if world > 1 or force_gather:
         import torch.distributed as dist
+        if force_gather and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29400 + os.getpid() % 500), RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from toyrenderer_amd import rhi
-    from toyrenderer_amd.frame import FrameDriver
+    from toyrenderer_amd import host, rhi
     from toyrenderer_amd.gather import VisibleListGather
 
-    stream = torch.cuda.current_stream().cuda_stream
-    dev = rhi.Device(local_rank, stream=stream)
+    # one side stream shared by the HIP back end and (N > 1) RCCL: torch's current stream
+    side = torch.cuda.Stream()
+    torch.cuda.set_stream(side)
+    stream = side.cuda_stream
     spec = synth.config_spec(args.config)
     view = synth.make_view(eye=(0.0, 0.0, 0.0), prev_eye=(0.05, 0.0, 0.1), prev_yaw=0.002)
     depth = synth.gen_depth(view, 200)
-
-    gs, (i0, i1), n_local, n_total, tested_upper = build_shard(spec, rank, world, dev, threads=min(8, os.cpu_count() or 1))
+    i0, i1 = shard_range(spec.num_instances, rank, world)
     groups_per_instance = (spec.meshlets_lod0 + 31) // 32
     record_cap = (i1 - i0) * groups_per_instance + 1
 
-    gather = VisibleListGather(dev, dist, world, rank, record_cap, record_cap * 32) if world > 1 else None
-    drv = FrameDriver(dev, gs, view, record_capacity=record_cap, list_capacity=record_cap * 32, culling_flags=args.flags,
-                      alloc=gather.alloc if gather else None)
-    drv.depth.upload_mip(0, depth)
+    # the drop-in path: C++ host mirror (Graphic / Scene / RenderGraph / BasePassRenderers) over the C ABI
+    r = host.Renderer(render=(view.renderW, view.renderH), device_index=local_rank, stream=stream,
+                      max_groups=record_cap, max_transient_bytes=8 << 30)
+    dev = rhi.Device(handle=r.device())
+    (i0, i1), n_local, n_total = build_shard(spec, rank, world, r, threads=min(8, os.cpu_count() or 1))
+    r.set_culling(args.flags)
+    r.upload_depth(depth)
+    gather = VisibleListGather(r, dist, world, rank, spec.num_instances * groups_per_instance + world) if dist is not None else None
 
     def step():
-        drv.record()
-        drv.run()
+        r.set_camera(view)
+        r.frame()
         if gather:
-            gather.run(drv)
+            gather.run()
 
     def sync():
         if dist is not None:
@@ -188,7 +191,7 @@ def main():
         dt = float(t.item())
 
     # work done per frame (device counters of the steady-state frame)
-    res = drv.results()
+    res = r.results()
     tested = 0
     groups = 0
     visible = 0
@@ -198,14 +201,23 @@ def main():
         recs = res[s]["records"]
         groups += len(recs)
         visible += int(res[s]["drawArgs"][0])
-        nm = gs_num_meshlets(spec, recs)
-        tested += nm
+        tested += gs_num_meshlets(spec, recs)
     counts = np.array([tested, groups, visible], np.int64)
     if dist is not None:
         t = torch.tensor(counts, device="cuda")
         dist.all_reduce(t)
         counts = t.cpu().numpy()
     tested_all, groups_all, visible_all = (int(x) for x in counts)
+    gather_checked = None
+    if gather is not None and world == 1:
+        # 1-rank group: the gathered whole-scene lists must equal the local ones
+        gather_checked = True
+        for i, s_ in enumerate((0, 1)):
+            if res[s_] is None:
+                continue
+            g_rec, g_lst = gather.results(i)
+            gather_checked &= bool(np.array_equal(g_rec, res[s_]["records"].view(np.uint32).reshape(-1, 3)))
+            gather_checked &= bool(np.array_equal(g_lst, res[s_]["visibleList"]))
     ms_per_step = dt / args.steps * 1e3
     value = tested_all / (dt / args.steps) / 1e9
 
@@ -215,8 +227,8 @@ def main():
         dev.profile_reset()
         dev.profile_enable(True)
         for _ in range(5):
-            drv.record()
-            drv.run()
+            r.set_camera(view)
+            r.frame()
         dev.wait_idle()
         prof = dev.profile()
         dev.profile_enable(False)
@@ -254,11 +266,12 @@ def main():
                        "visible_per_frame": visible_all, "culling_flags": args.flags},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if gather_checked is not None:
+            out["gather_checked"] = gather_checked
     sync()
     if out is not None:
         print(json.dumps(out), flush=True)
-    drv.release()
-    gs.release()
+    r.shutdown()
     if dist is not None:
         dist.destroy_process_group()
 

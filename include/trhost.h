@@ -29,6 +29,9 @@ void trhost_shutdown(void);
 int  trhost_load_scene(const void* instances, uint32_t num_instances, const void* mesh_data, uint32_t num_meshes,
                        const void* meshlets, uint64_t num_meshlets, const uint32_t* opaque_ids, uint32_t num_opaque,
                        const uint32_t* alpha_mask_ids, uint32_t num_alpha_mask);
+/* Large scenes: pass meshlets = NULL to trhost_load_scene (allocation only) and stream the meshlet
+ * buffer in with this call. */
+int  trhost_upload_meshlets(uint64_t first_meshlet, const void* meshlets, uint64_t count);
 /* Node hierarchy for UpdateInstanceConstsRenderer (BasePassRenderers.cpp:64-104); enables the pass. */
 int  trhost_load_nodes(const void* node_local_transforms, uint32_t num_nodes, const uint32_t* primitive_to_node);
 int  trhost_set_node_transforms(const void* node_local_transforms, uint32_t num_nodes);

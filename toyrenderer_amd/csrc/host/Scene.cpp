@@ -62,7 +62,7 @@ void Scene::LoadFromArrays(const void* instances, uint32_t numInstances, const v
     g_Graphic.m_GlobalMeshDataBuffer = make("GlobalMeshDataBuffer", (uint64_t)numMeshes * sizeof(interop::MeshData), sizeof(interop::MeshData), false);
     upload(g_Graphic.m_GlobalMeshDataBuffer, meshData, (uint64_t)numMeshes * sizeof(interop::MeshData));
     g_Graphic.m_GlobalMeshletDataBuffer = make("GlobalMeshletDataBuffer", numMeshlets * sizeof(interop::MeshletData), sizeof(interop::MeshletData), false);
-    upload(g_Graphic.m_GlobalMeshletDataBuffer, meshlets, numMeshlets * sizeof(interop::MeshletData));
+    if (meshlets) upload(g_Graphic.m_GlobalMeshletDataBuffer, meshlets, numMeshlets * sizeof(interop::MeshletData));   // else: streamed in by the caller
     // Scene::UpdateInstanceIDsBuffers (Scene.cpp:282-362)
     m_OpaquePrimitiveIDs.assign(opaqueIds, opaqueIds + numOpaque);
     m_AlphaMaskPrimitiveIDs.assign(alphaMaskIds, alphaMaskIds + numAlphaMask);

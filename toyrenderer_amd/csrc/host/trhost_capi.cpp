@@ -69,6 +69,15 @@ int trhost_load_scene(const void* instances, uint32_t num_instances, const void*
     });
 }
 
+int trhost_upload_meshlets(uint64_t first_meshlet, const void* meshlets, uint64_t count)
+{
+    return guarded([&] {
+        check(g_Graphic.m_GlobalMeshletDataBuffer);
+        nvrhi::throwIfFailed(trhip_buffer_upload(g_Graphic.m_GlobalMeshletDataBuffer->native(), first_meshlet * sizeof(interop::MeshletData), meshlets,
+                                                 count * sizeof(interop::MeshletData)), "trhost_upload_meshlets");
+    });
+}
+
 int trhost_load_nodes(const void* node_local_transforms, uint32_t num_nodes, const uint32_t* primitive_to_node)
 {
     return guarded([&] { g_Scene->LoadNodes(node_local_transforms, num_nodes, primitive_to_node); });

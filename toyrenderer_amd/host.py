@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtoyrenderer_host.so")
 
 HOST_SYMBOLS = [
-    "trhost_last_error", "trhost_initialize", "trhost_shutdown", "trhost_load_scene", "trhost_load_nodes",
+    "trhost_last_error", "trhost_initialize", "trhost_shutdown", "trhost_load_scene", "trhost_upload_meshlets", "trhost_load_nodes",
     "trhost_set_node_transforms", "trhost_set_camera", "trhost_set_culling", "trhost_set_limits", "trhost_upload_depth",
     "trhost_upload_hzb_mip", "trhost_download_hzb_mip", "trhost_hzb_info", "trhost_frame", "trhost_wait_idle",
     "trhost_pass_buffers", "trhost_instance_buffer", "trhost_device", "trhost_render_graph_stats", "trhost_renderer_times",
@@ -48,6 +48,7 @@ def load() -> C.CDLL:
     L.trhost_initialize.argtypes = [C.c_int, u32, u32, vp]
     L.trhost_shutdown.restype = None
     L.trhost_load_scene.argtypes = [vp, u32, vp, u32, vp, u64, vp, u32, vp, u32]
+    L.trhost_upload_meshlets.argtypes = [u64, vp, u64]
     L.trhost_load_nodes.argtypes = [vp, u32, vp]
     L.trhost_set_node_transforms.argtypes = [vp, u32]
     L.trhost_set_camera.argtypes = [vp, vp, vp, C.c_float]
@@ -107,13 +108,20 @@ class Renderer:
         _check(L.trhost_hzb_info(C.byref(w), C.byref(h), C.byref(m)))
         self.hzb_w, self.hzb_h, self.hzb_mips = w.value, h.value, m.value
 
-    def load_scene(self, instances, meshData, meshlets, opaqueIds, alphaMaskIds):
-        a = [np.ascontiguousarray(x) for x in (instances, meshData, meshlets)]
+    def load_scene(self, instances, meshData, meshlets, opaqueIds, alphaMaskIds, num_meshlets: int | None = None):
+        """meshlets=None + num_meshlets: allocate only; stream the data in with upload_meshlets()."""
+        a = [np.ascontiguousarray(x) for x in (instances, meshData)]
+        ml = np.ascontiguousarray(meshlets) if meshlets is not None else None
         op = np.ascontiguousarray(opaqueIds, np.uint32)
         am = np.ascontiguousarray(alphaMaskIds, np.uint32)
-        _check(load().trhost_load_scene(a[0].ctypes.data, len(a[0]), a[1].ctypes.data, len(a[1]), a[2].ctypes.data, len(a[2]),
+        _check(load().trhost_load_scene(a[0].ctypes.data, len(a[0]), a[1].ctypes.data, len(a[1]),
+                                        ml.ctypes.data if ml is not None else None, len(ml) if ml is not None else int(num_meshlets),
                                         op.ctypes.data if op.size else None, op.size, am.ctypes.data if am.size else None, am.size))
         self.num_opaque, self.num_alpha = op.size, am.size
+
+    def upload_meshlets(self, first: int, meshlets):
+        ml = np.ascontiguousarray(meshlets)
+        _check(load().trhost_upload_meshlets(int(first), ml.ctypes.data, len(ml)))
 
     def load_nodes(self, nodes, prim_to_node):
         n = np.ascontiguousarray(nodes); p = np.ascontiguousarray(prim_to_node, np.uint32)

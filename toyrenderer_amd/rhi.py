@@ -304,10 +304,14 @@ class CommandList:
 
 
 class Device:
-    def __init__(self, index: int = 0, stream: int | None = None):
+    def __init__(self, index: int = 0, stream: int | None = None, handle: int | None = None):
+        """handle: wrap an existing trhip_device (e.g. the host library's, trhost_device()); not owned."""
         L = load()
         h = C.c_void_p()
-        if stream is None:
+        self.owned = handle is None
+        if handle is not None:
+            h = C.c_void_p(handle)
+        elif stream is None:
             _check(L.trhip_device_create(index, C.byref(h)))
         else:
             _check(L.trhip_device_create_on_stream(index, C.c_void_p(stream), C.byref(h)))
@@ -372,6 +376,6 @@ class Device:
         return out
 
     def destroy(self):
-        if self.h:
+        if self.h and self.owned:
             load().trhip_device_destroy(self.h)
-            self.h = None
+        self.h = None
