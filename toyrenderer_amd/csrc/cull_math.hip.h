@@ -129,8 +129,22 @@ struct OccSample
 {
     bool accept;              // sphere intersects the near plane -> visible (:48-49)
     float depthSphere;        // :79
-    uint32_t i00, i01, i10, i11;   // texel indices relative to Hzb::base
+    uint32_t i0, i1;          // texel index (relative to Hzb::base) of the footprint's left texel in row y0 / y1
+    bool pair;                // the footprint has a second column (x0 + 1)
 };
+
+// One 32-bit load fetches the two horizontally adjacent texels of a footprint row (the address is
+// only 2-byte aligned: gfx950 runs in unaligned-access mode).  The high half is texel x0 + 1; it is
+// ignored when the footprint has a single column (at the right edge it may belong to the next row or
+// to the mip's alignment padding, which is inside the allocation).
+__device__ __forceinline__ uint32_t loadTexelPair(const _Float16* base, uint32_t idx)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, base + idx, 4);
+    return v;
+}
+__device__ __forceinline__ float texelLo(uint32_t v) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(v & 0xFFFFu)); }
+__device__ __forceinline__ float texelHi(uint32_t v) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(v >> 16)); }
 
 // mipOff: the mip offset table (texels); the hot kernel passes a copy parked in LDS so that the
 // per-lane lookup is one ds_read instead of a select chain over kernel arguments.
@@ -156,6 +170,11 @@ __device__ __forceinline__ OccSample occlusionPrepare(F3 c, float r, float nearP
     aw = fma_(aw, -0.5f, 0.5f);
     float width = (az - ax) * (float)h.width;                        // :73
     float height = (aw - ay) * (float)h.height;                      // :74
+#ifdef TR_EXPERIMENT_NO_FOOTPRINT      // timing experiment only: skip level / footprint / address math
+    o.i0 = (uint32_t)(width + height); o.i1 = o.i0 & 1023u; o.i0 &= 1023u; o.pair = false;
+    o.depthSphere = div_(nearPlane, c.z - r);
+    return o;
+#endif
     int mip = hzbLevel(width, height, h.mips);                       // :75
     float u = (ax + az) * 0.5f, v = (ay + aw) * 0.5f;                // :78
     // SampleLevel footprint (see sampleHzbMin)
@@ -172,17 +191,22 @@ __device__ __forceinline__ OccSample occlusionPrepare(F3 c, float r, float nearP
     y0 = min(max(y0, 0), ym);
     x1 = wx1 ? x1 : x0;
     y1 = wy1 ? y1 : y0;
+#ifdef TR_EXPERIMENT_NO_MIPLUT
+    uint32_t base = (uint32_t)mip * 64u;
+#else
     uint32_t base = mipOff[mip];
-    o.i00 = base + (uint32_t)y0 * mw + (uint32_t)x0;
-    o.i01 = base + (uint32_t)y0 * mw + (uint32_t)x1;
-    o.i10 = base + (uint32_t)y1 * mw + (uint32_t)x0;
-    o.i11 = base + (uint32_t)y1 * mw + (uint32_t)x1;
+#endif
+    o.i0 = base + (uint32_t)y0 * mw + (uint32_t)x0;
+    o.i1 = base + (uint32_t)y1 * mw + (uint32_t)x0;
+    o.pair = x1 != x0;                                               // then x1 == x0 + 1
     o.depthSphere = div_(nearPlane, c.z - r);                           // :79
     return o;
 }
 
-__device__ __forceinline__ bool occlusionResolve(const OccSample& o, float d00, float d01, float d10, float d11)
+__device__ __forceinline__ bool occlusionResolve(const OccSample& o, uint32_t row0, uint32_t row1)
 {
+    float d00 = texelLo(row0), d10 = texelLo(row1);
+    float d01 = o.pair ? texelHi(row0) : d00, d11 = o.pair ? texelHi(row1) : d10;
     float depth = min_(min_(min_(d00, d01), d10), d11);
     return o.accept | (o.depthSphere >= depth);                      // :81
 }
@@ -192,7 +216,7 @@ __device__ __forceinline__ bool occlusionVisible(F3 c, float r, float nearPlane,
 {
     if ((c.z - nearPlane) < r) return true;                          // :48-49
     OccSample o = occlusionPrepare(c, r, nearPlane, P00, P11, h, h.mipOffset);
-    return occlusionResolve(o, (float)h.base[o.i00], (float)h.base[o.i01], (float)h.base[o.i10], (float)h.base[o.i11]);
+    return occlusionResolve(o, loadTexelPair(h.base, o.i0), loadTexelPair(h.base, o.i1));
 }
 
 // x / 255.0f for x in [0,255], correctly rounded (== IEEE division; verified exhaustively by

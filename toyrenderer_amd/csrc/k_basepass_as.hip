@@ -28,6 +28,7 @@
 //     cone test's ALU work;
 //   * the 64-bit ballot is the two groups' visibility masks (WaveActiveCountBits/WavePrefix-
 //     CountBits :116-120); masks and the batch popcount are written once per batch.
+#include <cstdlib>
 #include <type_traits>
 
 #include "cull_math.hip.h"
@@ -70,6 +71,10 @@ struct MeshletCullArgs
     // scratch
     uint32_t* batchSum;                           // per batch: visible meshlets -> exclusive prefix after scan
     uint32_t maxBatches;
+    // optional processing order written by the instance pass into the record buffer's sidecar
+    // (k_gpuculling.hip): {valid, count} header + a permutation of [0, count) sorted by screen tile
+    const uint32_t* permHeader;
+    const uint32_t* perm;
 };
 
 __device__ __forceinline__ uint32_t groupCount(const MeshletCullArgs& a)
@@ -79,25 +84,61 @@ __device__ __forceinline__ uint32_t groupCount(const MeshletCullArgs& a)
     return G < a.recordCapacity ? G : a.recordCapacity;
 }
 
-struct MeshletRegs { float4 sphere; uint32_t cone; };
+// A record's MeshletData (<= 32 x 32 B = 1 KB) is fetched as whole lines: per half-wave, lane `sub`
+// loads 16-byte chunk `sub` (instruction A: meshlets 0-15) and chunk `32 + sub` (instruction B:
+// meshlets 16-31) -- 512 contiguous bytes per half-wave and instruction, i.e. 16 L1 accesses per wave
+// instruction instead of 64 for a 32-byte-stride gather.  Chunk parity = which half of the struct:
+// an even lane holds two bounding spheres, its odd neighbour the matching cone words.  The pairs are
+// completed with one DPP lane swap: the even lane then tests meshlet sub/2, the odd lane meshlet
+// 16 + sub/2 (the ballot is un-permuted before it is stored).
+// Every lane always loads (lanes past the record's end re-read chunk 0): with no exec-masked or
+// conditional loads in the loop the compiler can count outstanding loads exactly and emits partial
+// s_waitcnt vmcnt(N) instead of vmcnt(0).
+struct MeshletRegs { float4 a, b; };
 
-// Every lane always loads (inactive lanes re-read a valid meshlet of the record, or meshlet 0):
-// with no exec-masked or conditional loads in the loop the compiler can count outstanding loads
-// exactly and emits partial s_waitcnt vmcnt(N) instead of vmcnt(0).
-__device__ __forceinline__ MeshletRegs loadMeshlet(const MeshletData* meshlets, uint32_t base, uint32_t count, uint32_t sub)
+__device__ __forceinline__ MeshletRegs loadMeshletChunks(const MeshletData* meshlets, uint32_t base, uint32_t count, uint32_t sub)
 {
-    const uint32_t last = count ? count - 1u : 0u;
-    const uint32_t idx = count ? base + (sub < last ? sub : last) : 0u;
-    const MeshletData* p = meshlets + idx;
+    const float4* p = reinterpret_cast<const float4*>(meshlets + (count ? base : 0u));
+    const uint32_t nChunks = count * 2u;
+    const uint32_t ja = sub < nChunks ? sub : 0u, jb = 32u + sub < nChunks ? 32u + sub : 0u;
     MeshletRegs m;
-    m.sphere = *reinterpret_cast<const float4*>(p);                                  // basepass.hlsl:65
-    m.cone = p->m_ConeAxisAndCutoff;
+    m.a = p[ja];                                                                     // basepass.hlsl:65
+    m.b = p[jb];
     return m;
 }
+
+__device__ __forceinline__ float swapWithNeighbour(float v)   // quad_perm [1,0,3,2]
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+
+// bits 0,2,4,... of x -> bits 0..31
+__device__ __forceinline__ uint32_t compressEvenBits(unsigned long long x)
+{
+    x &= 0x5555555555555555ull;
+    x = (x | (x >> 1)) & 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+    return (uint32_t)x;
+}
+
+#ifdef TR_STAMPS   // diagnostic build only: per-segment cycle shares (never shipped, never timed)
+__device__ unsigned long long g_stampSums[8];
+#define TR_STAMP(i) do { unsigned long long _t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); stampSum[i] += _t - stampLast; stampLast = _t; } while (0)
+#else
+#define TR_STAMP(i) do {} while (0)
+#endif
 
 template <bool FRUSTUM, bool OCCLUSION, bool CONE>
 __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
 {
+#ifdef TR_STAMPS
+    unsigned long long stampSum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stampLast = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     __shared__ RecordInfo s_recAll[kWaves][kBatch];
     __shared__ uint32_t s_gIdxAll[kWaves][kBatch];
     __shared__ uint32_t s_mipOff[16];
@@ -116,6 +157,10 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
     // one, wave w runs records {2*numWaves*s + 2*w + half} at step s.  All waves of the chip thus
     // walk a moving window of ~2*numWaves consecutive records (instead of numWaves windows 64 records
     // apart), which keeps the HZB texels touched at any one time close together (L2/L1 locality).
+    // Records are processed in screen-tile order when the instance pass published one for exactly
+    // this record count (any permutation of [0,G) is a valid processing order: masks are stored by
+    // record index); otherwise in record order.
+    const bool usePerm = a.permHeader != nullptr && a.permHeader[0] == 1u && a.permHeader[1] == G;
     const uint32_t numWaves = gridDim.x * kWaves;
     const uint32_t waveId = blockIdx.x * kWaves + wave;
     const uint32_t superSize = numWaves * kBatch;
@@ -123,6 +168,7 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
     for (uint32_t sb = 0; sb < numSuper; ++sb) {
         const uint32_t sbBase = sb * superSize;
         if (sbBase + 2 * waveId >= G) break;                                         // nothing left for this wave
+        TR_STAMP(0);   // between batches
         // ---- prologue: lane l resolves the record of step l/2, half l&1 (basepass.hlsl:52-58) ---
         {
             RecordInfo ri;
@@ -131,7 +177,8 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
             for (int i = 0; i < 12; ++i) ri.w[i] = 0.f;
 #pragma unroll
             for (int i = 0; i < 9; ++i) ri.adj[i] = 0.f;
-            const uint32_t g = sbBase + (lane >> 1) * 2 * numWaves + 2 * waveId + (lane & 1);
+            const uint32_t e = sbBase + (lane >> 1) * 2 * numWaves + 2 * waveId + (lane & 1);
+            const uint32_t g = e < G ? (usePerm ? a.perm[e] : e) : 0xFFFFFFFFu;
             s_gIdx[lane] = g;
             if (g < G) {
                 const MeshletAmplificationData rec = a.records[g];
@@ -169,16 +216,23 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        TR_STAMP(1);   // prologue
         // ---- main loop: two records per step, meshlet data two steps ahead ----------------------
-        MeshletRegs slotA = loadMeshlet(a.meshlets, s_rec[half].meshletBase, s_rec[half].count, sub);
-        MeshletRegs slotB = loadMeshlet(a.meshlets, s_rec[2 + half].meshletBase, s_rec[2 + half].count, sub);
+        MeshletRegs slotA = loadMeshletChunks(a.meshlets, s_rec[half].meshletBase, s_rec[half].count, sub);
+        MeshletRegs slotB = loadMeshletChunks(a.meshlets, s_rec[2 + half].meshletBase, s_rec[2 + half].count, sub);
+        const bool odd = (sub & 1u) != 0;
+        const uint32_t myMeshlet = odd ? 16u + (sub >> 1) : (sub >> 1);             // index inside the group
 
         auto step = [&](MeshletRegs& slot, uint32_t s, auto prefetch) {
+            TR_STAMP(7);   // loop overhead / previous tail
             const uint32_t r = 2 * s + half;                                         // record within the batch
             const RecordInfo& ri = s_rec[r];
-            const float4 sphere = slot.sphere;
-            const uint32_t cone = slot.cone;
-            bool vis = sub < ri.count;
+            // complete the (sphere, cone) pair with the neighbour lane
+            const float r0 = swapWithNeighbour(odd ? slot.a.x : slot.b.x);
+            const float r1 = swapWithNeighbour(slot.b.y), r2 = swapWithNeighbour(slot.b.z), r3 = swapWithNeighbour(slot.b.w);
+            const float4 sphere = odd ? make_float4(r0, r1, r2, r3) : slot.a;
+            const uint32_t cone = __float_as_uint(odd ? slot.b.x : r0);
+            bool vis = myMeshlet < ri.count;
             const cm::M43 W = { { ri.w[0], ri.w[1], ri.w[2] }, { ri.w[3], ri.w[4], ri.w[5] },
                                 { ri.w[6], ri.w[7], ri.w[8] }, { ri.w[9], ri.w[10], ri.w[11] } };
             const cm::F3 cw = cm::mulPoint({ sphere.x, sphere.y, sphere.z }, W);                   // :67
@@ -186,27 +240,45 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
             const float rad = sphere.w * ri.maxScale;                                              // :71
             if (FRUSTUM)
                 vis &= cm::frustumVisible(cv, rad, a.k.m_Frustum.x, a.k.m_Frustum.y, a.k.m_Frustum.z, a.k.m_Frustum.w); // :73
+            TR_STAMP(2);   // wait for data + exchange + transform + frustum
             cm::OccSample os;
-            _Float16 t00 = 0, t01 = 0, t10 = 0, t11 = 0;
+            uint32_t row0 = 0, row1 = 0;
             if (OCCLUSION) {                                                                       // :75-88 (Q4)
                 os = cm::occlusionPrepare(cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_mipOff);
-                t00 = a.hzb.base[os.i00]; t01 = a.hzb.base[os.i01];
-                t10 = a.hzb.base[os.i10]; t11 = a.hzb.base[os.i11];
+#if defined(TR_EXPERIMENT_ONE_TEXEL)       // timing experiments only (wrong results)
+                row0 = cm::loadTexelPair(a.hzb.base, os.i0);
+                row1 = row0;
+#elif defined(TR_EXPERIMENT_ALIGNED_TEXEL)
+                row0 = cm::loadTexelPair(a.hzb.base, os.i0 & ~1u);
+                row1 = cm::loadTexelPair(a.hzb.base, os.i1 & ~1u);
+#elif defined(TR_EXPERIMENT_NO_TEXEL)
+                row0 = os.i0; row1 = os.i1;
+#else
+                row0 = cm::loadTexelPair(a.hzb.base, os.i0);
+                row1 = cm::loadTexelPair(a.hzb.base, os.i1);
+#endif
             }
+            TR_STAMP(3);   // occlusion prepare + texel load issue
             if (decltype(prefetch)::value) {                                                       // prefetch step s+2 into this slot
                 const uint32_t rn = r + 4;
-                slot = loadMeshlet(a.meshlets, s_rec[rn].meshletBase, s_rec[rn].count, sub);
+                slot = loadMeshletChunks(a.meshlets, s_rec[rn].meshletBase, s_rec[rn].count, sub);
             }
             if (CONE)                                                                              // :90-108
                 vis &= !cm::coneBackfacing(cone, cv, rad, { ri.adj[0], ri.adj[1], ri.adj[2] },
                                            { ri.adj[3], ri.adj[4], ri.adj[5] }, { ri.adj[6], ri.adj[7], ri.adj[8] }, V);
+            TR_STAMP(4);   // prefetch issue + cone
             if (OCCLUSION)
-                vis &= cm::occlusionResolve(os, (float)t00, (float)t01, (float)t10, (float)t11);
+                vis &= cm::occlusionResolve(os, row0, row1);
+            TR_STAMP(5);   // texel wait + resolve
             const unsigned long long ballot = __ballot(vis);                        // :116,120 WavePrefix/ActiveCountBits
+            // even lanes tested meshlets 0-15, odd lanes 16-31: put the bits back in meshlet order
+            const uint32_t lo16 = compressEvenBits(ballot), hi16 = compressEvenBits(ballot >> 1);
+            const uint32_t mask = half ? ((lo16 >> 16) | (hi16 & 0xFFFF0000u)) : ((lo16 & 0xFFFFu) | (hi16 << 16));
             if (sub == 0) {
                 const uint32_t g = s_gIdx[r];
-                if (g < G) a.visMask[g] = (uint32_t)(ballot >> (half * 32));
+                if (g < G) a.visMask[g] = mask;
             }
+            TR_STAMP(6);   // ballot + mask store
         };
 #pragma unroll 1
         for (uint32_t s = 0; s < kSteps - 2; s += 2) {
@@ -216,6 +288,10 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
         step(slotA, kSteps - 2, std::false_type{});
         step(slotB, kSteps - 1, std::false_type{});
     }
+#ifdef TR_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_stampSums[i], stampSum[i]);
+#endif
 }
 
 // Visible meshlets per batch of 64 consecutive records (canonical order): one wave per batch.
@@ -375,13 +451,19 @@ int recordASMain(trhip::DispatchCtx& ctx)
     const uint64_t lcap = visList->byteSize / 4;
     a.listCapacity = lcap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)lcap;
     a.drawArgs = (uint32_t*)drawArgs->ptr;
+    if (records->sidecar && records->sidecarBytes >= 256 + (uint64_t)a.recordCapacity * 4) {
+        a.permHeader = (const uint32_t*)records->sidecar;
+        a.perm = a.permHeader + 64;
+    }
     a.maxBatches = (a.recordCapacity + kBatch - 1) / kBatch;
     a.batchSum = (uint32_t*)ctx.scratch((size_t)a.maxBatches * 4);
     TRHIP_REQUIRE(a.batchSum, "%s: scratch allocation failed", ctx.shaderName);
 
     // Persistent grid: the group count lives on the device (indirect), so launch enough
     // workgroups to fill the chip and let them stride over the chunks.
-    uint32_t grid = ctx.computeUnits() * 6u;       // 6 workgroups per CU are resident (25.6 KB LDS each)
+    uint32_t blocksPerCU = 3u;                     // measured best (sweep 1..6: 1.00/0.76/0.70/0.72/-/0.74 ms); up to 6 fit (25.6 KB LDS each)
+    if (const char* e = getenv("TRHIP_AS_BLOCKS_PER_CU")) blocksPerCU = (uint32_t)atoi(e) ? (uint32_t)atoi(e) : blocksPerCU;   // tuning experiments
+    uint32_t grid = ctx.computeUnits() * blocksPerCU;
     const uint32_t needBlocks = (a.maxBatches + kWaves - 1) / kWaves;
     if (grid > needBlocks) grid = needBlocks;
     if (grid == 0) grid = 1;
@@ -437,3 +519,15 @@ trhip::ShaderRegistrar r1("basepass_AS_Main LATE_CULL=1", recordASMain, 1);
 trhip::ShaderRegistrar r2("basepass_AS_Main_cull", recordASMain, 0);
 
 } // namespace
+
+#ifdef TR_STAMPS
+extern "C" int trhip_debug_read_stamps(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stampSums), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stampSums), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

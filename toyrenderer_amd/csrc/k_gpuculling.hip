@@ -50,7 +50,32 @@ struct InstanceCullArgs
     uint64_t* blockLateSubmit;      // per block: late | submits<<32 -> exclusive prefix after B
     uint32_t* bases;                // [0] X before the pass, [1] late count before the pass
     uint32_t numBlocks;
+    // screen-tile binning of the submitted instances (PROCESSING order of the meshlet pass only; the
+    // record order above is untouched).  tileCount: 1024 counters (zeroed before classify), turned
+    // into cursors by the scan kernel; perm lives in the records buffer's sidecar: {valid, count, ...}
+    // header (64 words) followed by one record index per group.
+    uint32_t* tileCount;
+    uint16_t* tileOf;               // per entry
+    uint32_t* permHeader;
+    uint32_t* perm;
+    uint32_t permCapacity;
 };
+
+constexpr uint32_t kTilesPerAxis = 32;
+constexpr uint32_t kNumTiles = kTilesPerAxis * kTilesPerAxis;
+constexpr uint32_t kTileReplicas = 32;            // counters are replicated (blockIdx % 32) to spread the atomics
+constexpr uint32_t kPermHeaderWords = 64;
+
+// Which 1/32 x 1/32 screen tile the instance's centre projects to.  Scheduling heuristic only
+// (approximate reciprocal, no exactness requirement): it never influences an output value.
+__device__ __forceinline__ uint32_t screenTile(cm::F3 cv, float P00, float P11)
+{
+    const float iz = __builtin_amdgcn_rcpf(cm::max_(cv.z, 1e-6f));
+    const float u = cm::fma_(cv.x * iz * P00, 0.5f, 0.5f), v = cm::fma_(cv.y * iz * P11, -0.5f, 0.5f);
+    const int tx = min(max((int)(u * (float)kTilesPerAxis), 0), (int)kTilesPerAxis - 1);
+    const int ty = min(max((int)(v * (float)kTilesPerAxis), 0), (int)kTilesPerAxis - 1);
+    return (uint32_t)ty * kTilesPerAxis + (uint32_t)tx;
+}
 
 template <int LATE>
 __device__ __forceinline__ uint32_t threadCount(const InstanceCullArgs& a)
@@ -77,7 +102,7 @@ __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v, uint32_t lane)
 
 // gpuculling.hlsl:105-178 up to the ordered side effects.
 template <int LATE>
-__device__ __forceinline__ uint32_t classify(const InstanceCullArgs& a, uint32_t id)
+__device__ __forceinline__ uint32_t classify(const InstanceCullArgs& a, uint32_t id, uint32_t* tileOut)
 {
     const GPUCullingPassConstants& k = a.k;
     const bool doFrustum = (k.m_CullingFlags & kCullingFlagFrustumCullingEnable) != 0;
@@ -123,6 +148,7 @@ __device__ __forceinline__ uint32_t classify(const InstanceCullArgs& a, uint32_t
     lod = lod < kMaxNumMeshLODs ? lod : kMaxNumMeshLODs - 1u;                       // never index past the struct
     const uint32_t numMeshlets = mesh.m_MeshLODDatas[lod].m_NumMeshlets;
     const uint32_t groups = (numMeshlets + kNumThreadsPerWave - 1u) / kNumThreadsPerWave; // DivideAndRoundUp
+    *tileOut = screenTile(cv, k.m_P00, k.m_P11);
     return kWordSubmit | (lod << 27) | (groups & kGroupMask);
 }
 
@@ -137,10 +163,14 @@ __global__ __launch_bounds__(kBlock) void instanceClassifyKernel(InstanceCullArg
     const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 
-    uint32_t word = 0;
-    if (t < n) word = classify<LATE>(a, a.ids[t]);
+    uint32_t word = 0, tile = 0;
+    if (t < n) word = classify<LATE>(a, a.ids[t], &tile);
 
     const uint32_t g = (word & kWordSubmit) ? (word & kGroupMask) : 0u;
+    if (g != 0) {
+        atomicAdd(&a.tileCount[tile * kTileReplicas + (blockIdx.x % kTileReplicas)], g);   // histogram of groups per screen tile
+        a.tileOf[t] = (uint16_t)tile;
+    }
     const uint32_t late = word >> 31;
     const uint32_t submit = (word >> 30) & 1u;
 
@@ -210,6 +240,39 @@ __global__ __launch_bounds__(1024) void instanceScanKernel(InstanceCullArgs a)
         }
         if (a.argsWords > 3) a.dispatchArgs[3] = X;           // valid records; the first dropped instance lowers it in C
         if (!LATE) *a.lateCount = baseLate + (uint32_t)s_carryLS;   // :165
+        // The tile-sorted processing order is published only when every group is emitted (no Q2 drop,
+        // pass started from a cleared counter) and fits: then it is a permutation of [0, X).
+        a.permHeader[0] = (baseX == 0 && X < a.maxGroups && X <= a.permCapacity) ? 1u : 0u;
+        a.permHeader[1] = X;
+    }
+    // tile histogram -> exclusive prefix (cursors for the emit kernel); thread = tile, its replicas are contiguous
+    {
+        __syncthreads();
+        const uint32_t lane = tid & 63u, wave = tid >> 6;
+        uint32_t rep[kTileReplicas];
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < kTileReplicas; i += 4) {
+            const uint4 v = *reinterpret_cast<const uint4*>(&a.tileCount[tid * kTileReplicas + i]);
+            rep[i] = v.x; rep[i + 1] = v.y; rep[i + 2] = v.z; rep[i + 3] = v.w;
+            c += v.x + v.y + v.z + v.w;
+        }
+        uint32_t inc = waveInclusiveScan(c, lane);
+        __shared__ uint32_t s_w[16];
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        uint32_t pre = 0;
+        for (uint32_t w = 0; w < wave; ++w) pre += s_w[w];
+        uint32_t run = pre + inc - c;
+#pragma unroll
+        for (uint32_t i = 0; i < kTileReplicas; i += 4) {
+            uint4 v;
+            v.x = run; run += rep[i];
+            v.y = run; run += rep[i + 1];
+            v.z = run; run += rep[i + 2];
+            v.w = run; run += rep[i + 3];
+            *reinterpret_cast<uint4*>(&a.tileCount[tid * kTileReplicas + i]) = v;
+        }
     }
 }
 
@@ -237,6 +300,11 @@ __global__ __launch_bounds__(kBlock) void instanceEmitKernel(InstanceCullArgs a)
     for (uint32_t i = 0; i < groups; ++i) {                                         // :76-84
         MeshletAmplificationData rec = { id, lod, i * kNumThreadsPerWave };
         a.records[off + i] = rec;
+    }
+    if (groups != 0) {                                                              // slot range in the tile-sorted order
+        const uint32_t p = atomicAdd(&a.tileCount[(uint32_t)a.tileOf[t] * kTileReplicas + (blockIdx.x % kTileReplicas)], groups);
+        for (uint32_t i = 0; i < groups; ++i)
+            if (p + i < a.permCapacity) a.perm[p + i] = off + i;
     }
 }
 
@@ -321,7 +389,27 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
     a.blockGroups = (uint32_t*)ctx.scratch((size_t)a.numBlocks * 4);
     a.blockLateSubmit = (uint64_t*)ctx.scratch((size_t)a.numBlocks * 8);
     a.bases = (uint32_t*)ctx.scratch(16);
-    TRHIP_REQUIRE(a.word && a.localOff && a.blockGroups && a.blockLateSubmit && a.bases, "%s: scratch allocation failed", ctx.shaderName);
+    a.tileCount = (uint32_t*)ctx.scratch(kNumTiles * kTileReplicas * 4);
+    a.tileOf = (uint16_t*)ctx.scratch((size_t)nMax * 2);
+    TRHIP_REQUIRE(a.word && a.localOff && a.blockGroups && a.blockLateSubmit && a.bases && a.tileCount && a.tileOf, "%s: scratch allocation failed", ctx.shaderName);
+    // sidecar of the amplification buffer: header + one u32 per record slot
+    {
+        const uint64_t need = (uint64_t)kPermHeaderWords * 4 + (uint64_t)a.maxGroups * 4;
+        if (records->sidecarBytes < need) {
+            if (records->sidecar) { (void)hipStreamSynchronize(ctx.cl->dev->stream); (void)hipFree(records->sidecar); records->sidecar = nullptr; records->sidecarBytes = 0; }
+            void* p = nullptr;
+            TRHIP_HIP(hipMalloc(&p, (size_t)need));
+            records->sidecar = p;
+            records->sidecarBytes = need;
+        }
+        a.permHeader = (uint32_t*)records->sidecar;
+        a.perm = a.permHeader + kPermHeaderWords;
+        a.permCapacity = a.maxGroups;
+    }
+    {
+        uint32_t* tc = a.tileCount;
+        ctx.emit("clear_tiles", [tc](hipStream_t s) { TRHIP_HIP(hipMemsetAsync(tc, 0, kNumTiles * kTileReplicas * 4, s)); return (int)TRHIP_OK; });
+    }
 
     ctx.emit("classify", [a](hipStream_t s) {
         hipLaunchKernelGGL(instanceClassifyKernel<LATE>, dim3(a.numBlocks), dim3(kBlock), 0, s, a);

@@ -308,6 +308,7 @@ void trhip_buffer_release(trhip_buffer b)
     if (!b) return;
     if (b->rc.fetch_sub(1) == 1) {
         if (b->owns && b->ptr) { (void)hipSetDevice(b->dev->index); (void)hipFree(b->ptr); }
+        if (b->sidecar) { (void)hipSetDevice(b->dev->index); (void)hipFree(b->sidecar); }
         if (b->heap) trhip_heap_release(b->heap);
         delete b;
     }

@@ -78,6 +78,11 @@ struct trhip_buffer_t
     bool owns = false;
     trhip_heap_t* heap = nullptr;
     std::vector<uint8_t> shadow; // current version of a volatile constant buffer (record time)
+    // Back-end private companion allocation (device memory, freed with the buffer).  Used by the
+    // instance-cull pass to hand the meshlet-cull pass a screen-tile-sorted PROCESSING order of the
+    // amplification records it wrote into this buffer (k_gpuculling.hip / k_basepass_as.hip).
+    void* sidecar = nullptr;
+    uint64_t sidecarBytes = 0;
     std::atomic<int> rc{1};
 };
 
