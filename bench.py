@@ -129,6 +129,12 @@ def main():
     ap.add_argument("--flags", type=int, default=7, help="culling flags (7 = frustum+occlusion+cone, the headline config)")
     args = ap.parse_args()
 
+    # The driver parses ONE JSON line from stdout; RCCL prints its version banner there.  Everything
+    # else goes to stderr: fd 1 is pointed at fd 2 and the JSON line is written to the saved fd.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -270,7 +276,8 @@ def main():
             out["gather_checked"] = gather_checked
     sync()
     if out is not None:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     r.shutdown()
     if dist is not None:
         dist.destroy_process_group()

@@ -168,6 +168,10 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
     for (uint32_t sb = 0; sb < numSuper; ++sb) {
         const uint32_t sbBase = sb * superSize;
         if (sbBase + 2 * waveId >= G) break;                                         // nothing left for this wave
+        // steps of this super-batch that still hold records for this wave (wave-uniform), rounded up to even
+        const uint32_t remaining = G - sbBase - 2 * waveId;
+        uint32_t nSteps = (remaining + 2 * numWaves - 1) / (2 * numWaves);
+        nSteps = nSteps < kSteps ? (nSteps + 1u) & ~1u : kSteps;
         TR_STAMP(0);   // between batches
         // ---- prologue: lane l resolves the record of step l/2, half l&1 (basepass.hlsl:52-58) ---
         {
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
         const bool odd = (sub & 1u) != 0;
         const uint32_t myMeshlet = odd ? 16u + (sub >> 1) : (sub >> 1);             // index inside the group
 
-        auto step = [&](MeshletRegs& slot, uint32_t s, auto prefetch) {
+        auto step = [&](MeshletRegs& slot, uint32_t s) {
             TR_STAMP(7);   // loop overhead / previous tail
             const uint32_t r = 2 * s + half;                                         // record within the batch
             const RecordInfo& ri = s_rec[r];
@@ -259,8 +263,8 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
 #endif
             }
             TR_STAMP(3);   // occlusion prepare + texel load issue
-            if (decltype(prefetch)::value) {                                                       // prefetch step s+2 into this slot
-                const uint32_t rn = r + 4;
+            {                                                                                      // prefetch step s+2 into this slot (past the
+                const uint32_t rn = r + 4 < kBatch ? r + 4 : kBatch - 1;                           //  end: a harmless re-read, keeps loads unconditional)
                 slot = loadMeshletChunks(a.meshlets, s_rec[rn].meshletBase, s_rec[rn].count, sub);
             }
             if (CONE)                                                                              // :90-108
@@ -281,12 +285,10 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
             TR_STAMP(6);   // ballot + mask store
         };
 #pragma unroll 1
-        for (uint32_t s = 0; s < kSteps - 2; s += 2) {
-            step(slotA, s, std::true_type{});
-            step(slotB, s + 1, std::true_type{});
+        for (uint32_t s = 0; s < nSteps; s += 2) {
+            step(slotA, s);
+            step(slotB, s + 1);
         }
-        step(slotA, kSteps - 2, std::false_type{});
-        step(slotB, kSteps - 1, std::false_type{});
     }
 #ifdef TR_STAMPS
     if (lane == 0)
@@ -320,30 +322,42 @@ __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v, uint32_t lane)
 }
 
 // One block: exclusive scan of the batch sums -> list offsets; total -> drawArgs.
-// Tiles of 1024 with a carry; a tile = wave scans + one LDS exchange (two barriers).
+// Tiles of 1024 with a carry; a tile = wave scans + one LDS exchange (two barriers).  The loads of 16
+// tiles are issued together so that their latency is paid once per 16 tiles, not once per tile.
 __global__ __launch_bounds__(1024) void visScanKernel(MeshletCullArgs a)
 {
-    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_wave[2][16];
     const uint32_t G = groupCount(a);
     const uint32_t numBatches = (G + kBatch - 1) / kBatch;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < numBatches; base += 1024) {
-        const uint32_t i = base + tid;
-        const uint32_t v = i < numBatches ? a.batchSum[i] : 0u;
-        const uint32_t inc = waveInclusiveScan(v, lane);
-        if (lane == 63) s_wave[wave] = inc;
-        __syncthreads();
-        uint32_t pre = 0, tot = 0;
+    uint32_t carry = 0, flip = 0;
+    for (uint32_t base = 0; base < numBatches; base += 16 * 1024) {
+        uint32_t vals[16];
 #pragma unroll
-        for (uint32_t w = 0; w < 16; ++w) {
-            const uint32_t x = s_wave[w];
-            if (w < wave) pre += x;
-            tot += x;
+        for (uint32_t k = 0; k < 16; ++k) {
+            const uint32_t i = base + k * 1024 + tid;
+            vals[k] = i < numBatches ? a.batchSum[i] : 0u;
         }
-        if (i < numBatches) a.batchSum[i] = carry + pre + inc - v;
-        carry += tot;
-        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) {
+            const uint32_t i = base + k * 1024 + tid;
+            if (base + k * 1024 < numBatches) {                                       // uniform
+                const uint32_t v = vals[k];
+                const uint32_t inc = waveInclusiveScan(v, lane);
+                if (lane == 63) s_wave[flip][wave] = inc;
+                __syncthreads();
+                uint32_t pre = 0, tot = 0;
+#pragma unroll
+                for (uint32_t w = 0; w < 16; ++w) {
+                    const uint32_t x = s_wave[flip][w];
+                    if (w < wave) pre += x;
+                    tot += x;
+                }
+                if (i < numBatches) a.batchSum[i] = carry + pre + inc - v;
+                carry += tot;
+                flip ^= 1u;                                                           // double-buffered exchange: one barrier per tile
+            }
+        }
     }
     if (tid == 0) {
         a.drawArgs[0] = carry;         // replaces DispatchMesh(numVisible,1,1) summed over groups (basepass.hlsl:120-121)
@@ -480,15 +494,53 @@ int recordASMain(trhip::DispatchCtx& ctx)
         default: launchCull<true, true, true>(a, grid, s); break;
         }
         return trhip::launchStatus("meshletCullKernel"); });
-    ctx.emit("count", [a, grid](hipStream_t s) {
-        hipLaunchKernelGGL(visCountKernel, dim3(grid), dim3(kBlock), 0, s, a);
+    uint32_t gridSmall = ctx.computeUnits() * 8u;      // count / expand: light kernels, one wave per 64 groups
+    if (gridSmall > needBlocks) gridSmall = needBlocks;
+    if (gridSmall == 0) gridSmall = 1;
+    ctx.emit("count", [a, gridSmall](hipStream_t s) {
+        hipLaunchKernelGGL(visCountKernel, dim3(gridSmall), dim3(kBlock), 0, s, a);
         return trhip::launchStatus("visCountKernel"); });
     ctx.emit("scan", [a](hipStream_t s) {
         hipLaunchKernelGGL(visScanKernel, dim3(1), dim3(1024), 0, s, a);
         return trhip::launchStatus("visScanKernel"); });
-    ctx.emit("expand", [a, grid](hipStream_t s) {
-        hipLaunchKernelGGL(visExpandKernel, dim3(grid), dim3(kBlock), 0, s, a);
+    ctx.emit("expand", [a, gridSmall](hipStream_t s) {
+        hipLaunchKernelGGL(visExpandKernel, dim3(gridSmall), dim3(kBlock), 0, s, a);
         return trhip::launchStatus("visExpandKernel"); });
+    return TRHIP_OK;
+}
+
+// Multi-GPU: {G0, V0, G1, V1} of the two opaque pass slots in one 16-byte buffer (one launch instead of
+// several host-side tensor operations); G = min(X, validRecords).
+__global__ void packCountsKernel(const uint32_t* args0, const uint32_t* draw0, const uint32_t* args1, const uint32_t* draw1,
+                                 uint32_t words0, uint32_t words1, uint32_t* out)
+{
+    if (threadIdx.x != 0) return;
+    uint32_t g0 = args0 ? args0[0] : 0u, g1 = args1 ? args1[0] : 0u;
+    if (args0 && words0 > 3 && args0[3] < g0) g0 = args0[3];
+    if (args1 && words1 > 3 && args1[3] < g1) g1 = args1[3];
+    out[0] = g0; out[1] = draw0 ? draw0[0] : 0u;
+    out[2] = g1; out[3] = draw1 ? draw1[0] : 0u;
+}
+
+int recordPackCounts(trhip::DispatchCtx& ctx)
+{
+    trhip_buffer_t* a0 = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 0);
+    trhip_buffer_t* d0 = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 1);
+    trhip_buffer_t* a1 = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 2);
+    trhip_buffer_t* d1 = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 3);
+    trhip_buffer_t* out = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 0);
+    TRHIP_REQUIRE(out && out->byteSize >= 16, "%s: needs UAV u0 (16 bytes)", ctx.shaderName);
+    TRHIP_REQUIRE((!a0 || a0->byteSize >= 12) && (!a1 || a1->byteSize >= 12) && (!d0 || d0->byteSize >= 12) && (!d1 || d1->byteSize >= 12),
+                  "%s: argument buffers smaller than 12 bytes", ctx.shaderName);
+    const uint32_t* pa0 = a0 ? (const uint32_t*)a0->ptr : nullptr;
+    const uint32_t* pd0 = d0 ? (const uint32_t*)d0->ptr : nullptr;
+    const uint32_t* pa1 = a1 ? (const uint32_t*)a1->ptr : nullptr;
+    const uint32_t* pd1 = d1 ? (const uint32_t*)d1->ptr : nullptr;
+    const uint32_t w0 = a0 && a0->byteSize >= 16 ? 4u : 3u, w1 = a1 && a1->byteSize >= 16 ? 4u : 3u;
+    uint32_t* po = (uint32_t*)out->ptr;
+    ctx.emit("main", [=](hipStream_t s) {
+        hipLaunchKernelGGL(packCountsKernel, dim3(1), dim3(64), 0, s, pa0, pd0, pa1, pd1, w0, w1, po);
+        return trhip::launchStatus("packCountsKernel"); });
     return TRHIP_OK;
 }
 
@@ -514,6 +566,7 @@ int recordRebase(trhip::DispatchCtx& ctx)
 }
 
 trhip::ShaderRegistrar rr("visibility_CS_RebaseVisibleList", recordRebase, 0);
+trhip::ShaderRegistrar rp("visibility_CS_PackCounts", recordPackCounts, 0);
 trhip::ShaderRegistrar r0("basepass_AS_Main LATE_CULL=0", recordASMain, 0);
 trhip::ShaderRegistrar r1("basepass_AS_Main LATE_CULL=1", recordASMain, 1);
 trhip::ShaderRegistrar r2("basepass_AS_Main_cull", recordASMain, 0);

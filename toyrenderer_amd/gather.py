@@ -86,6 +86,7 @@ class VisibleListGather:
         self.all_lists = [torch.empty(global_record_cap * 32, dtype=torch.int32, device="cuda") for _ in self.SLOTS]
         self.all_records = [torch.empty(global_record_cap * 3, dtype=torch.int32, device="cuda") for _ in self.SLOTS]
         self.counts_local = torch.zeros(2 * len(self.SLOTS), dtype=torch.int32, device="cuda")
+        self.counts_buf = self.dev.wrap_buffer(self.counts_local.data_ptr(), 16, "GatherCounts")
         self.cl = self.dev.create_command_list()
         self.last_counts = None
         self.totals = None
@@ -102,16 +103,22 @@ class VisibleListGather:
         return t
 
     def run(self):
-        torch, L = self.torch, self.rhi.load()
+        torch, L, rhi = self.torch, self.rhi.load(), self.rhi
         pbs = [self.r.pass_buffers(s) for s in self.SLOTS]
+        # 1. {G0, V0, G1, V1} with one tiny kernel into a torch-owned 16-byte tensor
+        cl = self.cl
+        cl.open()
+        b = []
         for i, pb in enumerate(pbs):
-            if not pb.ran:
-                self.counts_local[2 * i:2 * i + 2] = 0
-                continue
-            a = self._tensor(pb.dispatch_args, 4)
-            self.counts_local[2 * i] = torch.minimum(a[0], a[3])           # G = min(X, validRecords)
-            self.counts_local[2 * i + 1] = self._tensor(pb.draw_args, 3)[0]
-        c = exchange_counts(self.dist, torch, self.counts_local, self.world)
+            if pb.ran:
+                x, y = rhi.bind(rhi.BIND_STRUCTURED_SRV, 2 * i), rhi.bind(rhi.BIND_STRUCTURED_SRV, 2 * i + 1)
+                x.resource, y.resource = pb.dispatch_args, pb.draw_args
+                b += [x, y]
+        b.append(rhi.UAV(0, self.counts_buf))
+        cl.dispatch("visibility_CS_PackCounts", b, (1, 1, 1))
+        cl.close()
+        self.dev.execute(cl)
+        c = exchange_counts(self.dist, torch, self.counts_local, self.world)          # 2. the frame's one host sync
         self.last_counts = c
         self.totals = []
         for i, pb in enumerate(pbs):
@@ -122,15 +129,14 @@ class VisibleListGather:
             lst = self._tensor(pb.visible_list, L.trhip_buffer_size(pb.visible_list) // 4)
             rec = self._tensor(pb.records, L.trhip_buffer_size(pb.records) // 4)
 
-            def rebase(add, pb=pb):
-                cl = self.cl
+            def rebase(add, pb=pb):                                                    # 3. rebase own entries (HIP kernel)
                 cl.open()
-                b = [self.rhi.PUSH(0), self.rhi.bind(self.rhi.BIND_STRUCTURED_UAV, 0), self.rhi.bind(self.rhi.BIND_STRUCTURED_SRV, 0)]
-                b[1].resource, b[2].resource = pb.visible_list, pb.draw_args
-                cl.dispatch("visibility_CS_RebaseVisibleList", b, (1, 1, 1), push=np.array([add >> 5], np.uint32))
+                bb = [rhi.PUSH(0), rhi.bind(rhi.BIND_STRUCTURED_UAV, 0), rhi.bind(rhi.BIND_STRUCTURED_SRV, 0)]
+                bb[1].resource, bb[2].resource = pb.visible_list, pb.draw_args
+                cl.dispatch("visibility_CS_RebaseVisibleList", bb, (1, 1, 1), push=np.array([add >> 5], np.uint32))
                 cl.close()
                 self.dev.execute(cl)
-            self.totals.append(gather_slot(self.dist, self.rank, self.world, self.all_lists[i], self.all_records[i], lst, rec, G, V, rebase, True))
+            self.totals.append(gather_slot(self.dist, self.rank, self.world, self.all_lists[i], self.all_records[i], lst, rec, G, V, rebase, True))   # 4.
 
     def results(self, slot_index: int):
         G, V = self.totals[slot_index]
