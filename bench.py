@@ -167,7 +167,7 @@ def main():
     r = host.Renderer(render=(view.renderW, view.renderH), device_index=local_rank, stream=stream,
                       max_groups=record_cap, max_transient_bytes=8 << 30)
     dev = rhi.Device(handle=r.device())
-    (i0, i1), n_local, n_total = build_shard(spec, rank, world, r, threads=min(8, os.cpu_count() or 1))
+    (i0, i1), n_local, n_total = build_shard(spec, rank, world, r, threads=min(8, host_threads()))
     r.set_culling(args.flags)
     r.upload_depth(depth)
     gather = VisibleListGather(r, dist, world, rank, spec.num_instances * groups_per_instance + world) if dist is not None else None
@@ -248,8 +248,17 @@ def main():
         # + 68 B (world matrix + mesh index) per submitted instance
         alg_bytes = 32 * t0_tested + 16 * len(r0["records"]) + 68 * inst_submitted
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, committed summary):
+        # only valid for the exact workload it was measured on
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r1", "traffic.json")))
+            if tj["config"] == args.config and tj["culling_flags"] == args.flags and tj["kernel"] == DOMINANT and world == 1:
+                traffic = int(tj["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = dict(bound="hbm", kernel=DOMINANT, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, avg_launch_ms=round(avg_ms, 4),
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, avg_launch_ms=round(avg_ms, 4),
                         algorithmic_bytes_per_launch=int(alg_bytes), meshlets_per_launch=int(t0_tested),
                         per_kernel_ms={k: round(v[1] / v[0], 4) for k, v in prof.items()})
 
@@ -258,7 +267,7 @@ def main():
         cpu = None
         if not args.no_cpu_baseline:
             try:
-                cpu = cpu_baseline(spec, view, depth, args.cpu_sample_instances, os.cpu_count() or 1)
+                cpu = cpu_baseline(spec, view, depth, args.cpu_sample_instances, host_threads())
             except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU number
                 cpu = dict(error=str(e))
         out = {
@@ -281,6 +290,15 @@ def main():
     r.shutdown()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def host_threads() -> int:
+    """Host cores this process may use (the GPU box gives one GPU's share of the node's cores)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 64))
 
 
 def gs_num_meshlets(spec, recs) -> int:

@@ -553,13 +553,17 @@ uint64_t orc_meshlet_cull(const OrcBasePassConstants* k,
 /* HZB build                                                                            */
 /* ------------------------------------------------------------------------------------ */
 
-void orc_hzb_build(const float* depth, uint32_t W, uint32_t H,
-                   uint16_t* texels, uint32_t hw, uint32_t hh, uint32_t mips, const uint64_t* mipOffset)
+typedef struct { const float* depth; uint32_t W, H; uint16_t* m0; uint32_t hw, hh, y0, y1; } HzbMip0Job;
+
+static void* hzb_mip0_rows(void* p)
 {
     /* minmaxdownsample.hlsl:15-34 with m_bDownsampleMax = 0 (BasePassRenderers.cpp:517):
      * uv = (tid + 0.5) / outDim; Gather = the 2x2 quad floor(uv*dim - 0.5) + {0,1}, clamped (Q11). */
-    uint16_t* m0 = texels + mipOffset[0];
-    for (uint32_t y = 0; y < hh; ++y) {
+    const HzbMip0Job* j = (const HzbMip0Job*)p;
+    const float* depth = j->depth;
+    const uint32_t W = j->W, H = j->H, hw = j->hw, hh = j->hh;
+    uint16_t* m0 = j->m0;
+    for (uint32_t y = j->y0; y < j->y1; ++y) {
         float v = ((float)y + 0.5f) / (float)hh;
         float fy = fmaf(v, (float)H, -0.5f);
         int y0 = (int)floorf(fy), y1 = y0 + 1;
@@ -577,6 +581,28 @@ void orc_hzb_build(const float* depth, uint32_t W, uint32_t H,
             m0[(uint64_t)y * hw + x] = orc_f32_to_f16(mn);
         }
     }
+    return 0;
+}
+
+static void hzb_build_mt(const float* depth, uint32_t W, uint32_t H,
+                         uint16_t* texels, uint32_t hw, uint32_t hh, uint32_t mips, const uint64_t* mipOffset, uint32_t threads)
+{
+    uint16_t* m0 = texels + mipOffset[0];
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    if (threads > hh) threads = hh ? hh : 1;
+    if (threads == 1) {
+        HzbMip0Job j = { depth, W, H, m0, hw, hh, 0, hh };
+        hzb_mip0_rows(&j);
+    } else {
+        pthread_t th[256]; HzbMip0Job jobs[256];
+        for (uint32_t i = 0; i < threads; ++i) {
+            HzbMip0Job j = { depth, W, H, m0, hw, hh, (uint32_t)((uint64_t)hh * i / threads), (uint32_t)((uint64_t)hh * (i + 1) / threads) };
+            jobs[i] = j;
+            pthread_create(&th[i], 0, hzb_mip0_rows, &jobs[i]);
+        }
+        for (uint32_t i = 0; i < threads; ++i) pthread_join(th[i], 0);
+    }
     /* SPD min filter (FFXHelpers.cpp:108): mip k+1 texel = min of the 2x2 block of mip k. */
     for (uint32_t k = 1; k < mips; ++k) {
         uint32_t pw = (hw >> (k - 1)) ? (hw >> (k - 1)) : 1u, ph = (hh >> (k - 1)) ? (hh >> (k - 1)) : 1u;
@@ -592,6 +618,12 @@ void orc_hzb_build(const float* depth, uint32_t W, uint32_t H,
                 dst[(uint64_t)y * mw + x] = orc_f32_to_f16(fminf(fminf(a, b), fminf(c, d)));
             }
     }
+}
+
+void orc_hzb_build(const float* depth, uint32_t W, uint32_t H,
+                   uint16_t* texels, uint32_t hw, uint32_t hh, uint32_t mips, const uint64_t* mipOffset)
+{
+    hzb_build_mt(depth, W, H, texels, hw, hh, mips, mipOffset, 1);
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -730,12 +762,12 @@ void orc_frame(OrcFrameDesc* d, OrcFrameOut* o)
     run_pass(d, o, 0, 0, 0, flags, frustum, &hzb);                          /* :565-566 */
     if (occlusion) {
         if (!d->freezeCullingCamera)                                        /* :507-510, :570 */
-            orc_hzb_build(d->depth, d->depthW, d->depthH, d->hzbTexels, d->hzbW, d->hzbH, d->hzbMips, d->hzbMipOffset);
+            hzb_build_mt(d->depth, d->depthW, d->depthH, d->hzbTexels, d->hzbW, d->hzbH, d->hzbMips, d->hzbMipOffset, d->threads);
         run_pass(d, o, 1, 1, 0, flags, frustum, &hzb);                      /* :572-573 */
         run_pass(d, o, 2, 0, 1, flags, frustum, &hzb);                      /* :575-576 (Q12) */
         run_pass(d, o, 3, 1, 1, flags, frustum, &hzb);                      /* :577-578 */
         if (!d->freezeCullingCamera)                                        /* :580 */
-            orc_hzb_build(d->depth, d->depthW, d->depthH, d->hzbTexels, d->hzbW, d->hzbH, d->hzbMips, d->hzbMipOffset);
+            hzb_build_mt(d->depth, d->depthW, d->depthH, d->hzbTexels, d->hzbW, d->hzbH, d->hzbMips, d->hzbMipOffset, d->threads);
     } else {
         run_pass(d, o, 2, 0, 1, flags, frustum, &hzb);                      /* :585-586 */
     }

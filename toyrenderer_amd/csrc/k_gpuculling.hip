@@ -195,38 +195,48 @@ __global__ __launch_bounds__(kBlock) void instanceClassifyKernel(InstanceCullArg
     }
 }
 
-// One block: exclusive scan over the per-block sums; final counters.
+// One block: exclusive scan over the per-block sums; final counters.  Tiles of 1024 entries: wave
+// scans + one LDS exchange per tile; only the blocks that had threads (device-side count) are visited.
 template <int LATE>
 __global__ __launch_bounds__(1024) void instanceScanKernel(InstanceCullArgs a)
 {
-    __shared__ uint32_t s_g[1024];
-    __shared__ uint64_t s_ls[1024];
+    __shared__ uint32_t s_wg[2][16];
+    __shared__ uint64_t s_wls[2][16];
     __shared__ uint32_t s_carryG;
     __shared__ uint64_t s_carryLS;
-    const uint32_t tid = threadIdx.x;
-    if (tid == 0) { s_carryG = 0; s_carryLS = 0; }
-    __syncthreads();
-    for (uint32_t base = 0; base < a.numBlocks; base += 1024) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n = threadCount<LATE>(a);
+    const uint32_t activeBlocks = (n + kBlock - 1) / kBlock < a.numBlocks ? (n + kBlock - 1) / kBlock : a.numBlocks;
+    uint32_t carryG = 0, flip = 0;
+    uint64_t carryLS = 0;
+    for (uint32_t base = 0; base < activeBlocks; base += 1024) {
         const uint32_t i = base + tid;
-        const uint32_t g = i < a.numBlocks ? a.blockGroups[i] : 0u;
-        const uint64_t ls = i < a.numBlocks ? a.blockLateSubmit[i] : 0ull;
-        s_g[tid] = g; s_ls[tid] = ls;
+        const uint32_t g = i < activeBlocks ? a.blockGroups[i] : 0u;
+        const uint64_t ls = i < activeBlocks ? a.blockLateSubmit[i] : 0ull;
+        const uint32_t incG = waveInclusiveScan(g, lane);
+        // 64-bit inclusive scan of (late | submits << 32): two 32-bit halves, no carry between them (each < 2^32)
+        const uint32_t incLo = waveInclusiveScan((uint32_t)ls, lane), incHi = waveInclusiveScan((uint32_t)(ls >> 32), lane);
+        const uint64_t incLS = (uint64_t)incLo | ((uint64_t)incHi << 32);
+        if (lane == 63) { s_wg[flip][wave] = incG; s_wls[flip][wave] = incLS; }
         __syncthreads();
-        for (uint32_t d = 1; d < 1024; d <<= 1) {            // Hillis-Steele, 10 steps
-            uint32_t pg = tid >= d ? s_g[tid - d] : 0u;
-            uint64_t pl = tid >= d ? s_ls[tid - d] : 0ull;
-            __syncthreads();
-            s_g[tid] += pg; s_ls[tid] += pl;
-            __syncthreads();
+        uint32_t preG = 0, totG = 0;
+        uint64_t preLS = 0, totLS = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16; ++w) {
+            const uint32_t xg = s_wg[flip][w];
+            const uint64_t xl = s_wls[flip][w];
+            if (w < wave) { preG += xg; preLS += xl; }
+            totG += xg; totLS += xl;
         }
-        if (i < a.numBlocks) {
-            a.blockGroups[i] = s_carryG + s_g[tid] - g;
-            a.blockLateSubmit[i] = s_carryLS + s_ls[tid] - ls;
+        if (i < activeBlocks) {
+            a.blockGroups[i] = carryG + preG + incG - g;
+            a.blockLateSubmit[i] = carryLS + preLS + incLS - ls;
         }
-        __syncthreads();
-        if (tid == 1023) { s_carryG += s_g[1023]; s_carryLS += s_ls[1023]; }
-        __syncthreads();
+        carryG += totG; carryLS += totLS;
+        flip ^= 1u;
     }
+    if (tid == 0) { s_carryG = carryG; s_carryLS = carryLS; }
+    __syncthreads();
     if (tid == 0) {
         const uint32_t baseX = a.dispatchArgs[0];
         const uint32_t baseLate = LATE ? 0u : *a.lateCount;
