@@ -6,7 +6,8 @@
 A step = one full 2-phase visibility frame (BasePassRenderer::RenderBasePass,
 source/BasePassRenderers.cpp:544-588) over the scene shard(s) resident in HBM: early instance
 cull -> early meshlet cull -> HZB build -> late instance cull -> late meshlet cull -> HZB build
-[-> RCCL all-gather of the per-rank visible lists when N > 1].  value = meshlets tested per frame
+[-> when N > 1: RCCL all-gather of every rank's records + visibility masks (shard slots) and rebuild
+of the whole-scene visible lists on every rank, overlapped with the next frame's culling].  value = meshlets tested per frame
 (all ranks) / max-over-ranks frame time.  Scaling is STRONG: the 100 M-meshlet scene is fixed and
 its instances are sharded over the ranks (north_star).
 
@@ -150,9 +151,9 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from toyrenderer_amd import host, rhi
-    from toyrenderer_amd.gather import VisibleListGather
+    from toyrenderer_amd.gather import HipShardExchange
 
-    # one side stream shared by the HIP back end and (N > 1) RCCL: torch's current stream
+    # the HIP back end's stream = torch's current stream; (N > 1) the exchange adds its own second stream
     side = torch.cuda.Stream()
     torch.cuda.set_stream(side)
     stream = side.cuda_stream
@@ -170,7 +171,13 @@ def main():
     (i0, i1), n_local, n_total = build_shard(spec, rank, world, r, threads=min(8, host_threads()))
     r.set_culling(args.flags)
     r.upload_depth(depth)
-    gather = VisibleListGather(r, dist, world, rank, spec.num_instances * groups_per_instance + world) if dist is not None else None
+    gather = None
+    if dist is not None:
+        # one slot size for all ranks: the largest shard, every instance submitted at LOD 0
+        slot_groups = max(b - a for a, b in (shard_range(spec.num_instances, p, world) for p in range(world))) * groups_per_instance
+        gather = HipShardExchange(r, dist, world, rank, slot_groups, pass_slots=(0, 1),
+                                  group_capacity=spec.num_instances * groups_per_instance,
+                                  overlap=not os.environ.get("TR_NO_OVERLAP"))
 
     def step():
         r.set_camera(view)
@@ -179,6 +186,7 @@ def main():
             gather.run()
 
     def sync():
+        torch.cuda.synchronize()          # all streams of the device, including the exchange's
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -221,7 +229,7 @@ def main():
         for i, s_ in enumerate((0, 1)):
             if res[s_] is None:
                 continue
-            g_rec, g_lst = gather.results(i)
+            g_rec, g_lst = gather.results(s_)
             gather_checked &= bool(np.array_equal(g_rec, res[s_]["records"].view(np.uint32).reshape(-1, 3)))
             gather_checked &= bool(np.array_equal(g_lst, res[s_]["visibleList"]))
     ms_per_step = dt / args.steps * 1e3
@@ -276,7 +284,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: synthetic {n_total} unique meshlets ({spec.num_instances} instances x {spec.meshlets_lod0}), "
                                    "2-phase frustum+HZB+cone cull, 3840x2160 -> 2048x2048 R16F HZB, instances sharded over ranks"
-                                   + (" + RCCL all-gather of visible lists" if world > 1 else ""),
+                                   + (" + RCCL all-gather of per-rank records and visibility masks, whole-scene lists rebuilt on every rank" if world > 1 else ""),
                        "meshlets_in_scene": n_total, "meshlets_tested_per_frame": tested_all, "groups_per_frame": groups_all,
                        "visible_per_frame": visible_all, "culling_flags": args.flags},
             "roofline": roofline, "cpu_baseline": cpu,
@@ -287,6 +295,8 @@ def main():
     if out is not None:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if gather is not None:
+        gather.close()
     r.shutdown()
     if dist is not None:
         dist.destroy_process_group()

@@ -148,6 +148,12 @@ int  trhip_cmd_write_buffer(trhip_cmdlist cl, trhip_buffer buf, uint64_t dst_off
 int  trhip_cmd_clear_buffer_u32(trhip_cmdlist cl, trhip_buffer buf, uint32_t value);   /* ::clearBufferUInt   */
 int  trhip_cmd_clear_texture_f32(trhip_cmdlist cl, trhip_texture tex, float value);    /* ::clearTextureFloat */
 int  trhip_cmd_copy_buffer(trhip_cmdlist cl, trhip_buffer dst, uint64_t dst_offset, trhip_buffer src, uint64_t src_offset, uint64_t bytes); /* ::copyBuffer */
+/* Multi-GPU hook (no counterpart in the reference, which is single-GPU: GraphicRHI.cpp:165).
+ * fn(user, hip_stream) is called on the submitting thread while the list is executed, in order with
+ * the surrounding commands: whatever fn enqueues on hip_stream runs after everything recorded before
+ * it and before everything recorded after it.  fn must not execute lists on / wait for this device. */
+typedef void (*trhip_host_fn)(void* user, void* hip_stream);
+int  trhip_cmd_host_callback(trhip_cmdlist cl, trhip_host_fn fn, void* user);
 /* ::copyTexture, whole mip chain; both textures must have identical dimensions, mips and format. */
 int  trhip_cmd_copy_texture(trhip_cmdlist cl, trhip_texture dst, trhip_texture src);
 /* ::setComputeState + ::setPushConstants + ::dispatch(gx,gy,gz) (Graphic.cpp:893-947).
@@ -183,6 +189,14 @@ int  trhip_profile_enable(trhip_device dev, int enabled);
 int  trhip_profile_reset(trhip_device dev);
 int  trhip_profile_count(trhip_device dev, uint32_t* n);
 int  trhip_profile_entry(trhip_device dev, uint32_t index, const char** name, uint64_t* launches, double* total_ms);
+
+/* Multi-GPU late phase.  The reference sizes the late instance cull from the late-list length
+ * (gpuculling.hlsl:182-195, Q1: ceil(count/64) groups of 32 threads).  With the instance list sharded
+ * over ranks that rule has to see the WHOLE scene's late list: every rank all-gathers its late count,
+ * then this kernel writes info = { sum of counts[0..rank), sum of counts[0..world) } on hip_stream.
+ * The late "gpuculling_CS_GPUCulling LATE_CULL=1" dispatch reads it from an optional SRV t4 and
+ * processes exactly the entries the single-GPU dispatch would. */
+int  trhip_launch_shard_late_info(void* hip_stream, const uint32_t* gathered_counts, uint32_t world, uint32_t rank, uint32_t* info);
 
 #ifdef __cplusplus
 }

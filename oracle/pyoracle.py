@@ -61,7 +61,8 @@ class FrameDesc(C.Structure):
                 ("hzbTexels", C.c_void_p), ("hzbW", C.c_uint32), ("hzbH", C.c_uint32), ("hzbMips", C.c_uint32),
                 ("hzbMipOffset", C.c_uint64 * MAX_MIPS),
                 ("depth", C.c_void_p), ("depthW", C.c_uint32), ("depthH", C.c_uint32),
-                ("threads", C.c_uint32)]
+                ("threads", C.c_uint32),
+                ("shardLate", C.c_uint32), ("shardLateBase", C.c_uint32 * 2), ("shardLateTotal", C.c_uint32 * 2)]
 
 
 class FrameOut(C.Structure):
@@ -266,7 +267,7 @@ class FrameResult:
 
 
 def frame(scene: dict, view: dict, hzb: HzbTexture, depth: np.ndarray | None, *, cullingFlags=7, forceMeshLOD=-1,
-          freeze=False, maxGroups=65535, threads=1, record_capacity=None, list_capacity=None) -> FrameResult:
+          freeze=False, maxGroups=65535, threads=1, record_capacity=None, list_capacity=None, shard_late=None) -> FrameResult:
     """Run BasePassRenderer::RenderBasePass on the CPU.  `scene`: instances, meshData, meshlets,
     opaqueIds, alphaMaskIds (numpy, wire dtypes).  `view`: worldToView, prevWorldToView, viewToClip,
     nearPlane, renderHeight.  hzb is updated in place (it is the previous frame's on entry)."""
@@ -289,6 +290,10 @@ def frame(scene: dict, view: dict, hzb: HzbTexture, depth: np.ndarray | None, *,
         depth = np.ascontiguousarray(depth, np.float32)
         d.depth, d.depthH, d.depthW = _p(depth), depth.shape[0], depth.shape[1]
     d.threads = int(threads)
+    if shard_late is not None:      # multi-GPU checker: ((base_opaque, total_opaque), (base_alpha, total_alpha))
+        d.shardLate = 1
+        for b in (0, 1):
+            d.shardLateBase[b], d.shardLateTotal[b] = int(shard_late[b][0]), int(shard_late[b][1])
 
     if record_capacity is None:
         lods = md[md.dtype.names[1]]

@@ -403,7 +403,8 @@ static void instance_cull_mt(const OrcGPUCullingPassConstants* k, int lateCull,
                              const OrcMeshData* meshData, const OrcHZB* hzb,
                              OrcMeshletAmplificationData* records, uint32_t dispatchArgs[3],
                              uint32_t* lateCount, uint32_t* lateIds, uint32_t lateDispatchArgsX,
-                             uint32_t maxGroups, uint32_t* validRecords, uint32_t threads)
+                             uint32_t maxGroups, uint32_t* validRecords, uint32_t threads,
+                             const uint32_t* shardLate /* NULL or {base, total} (multi-GPU checker) */)
 {
     /* :94-103 thread range */
     uint32_t nbInstances = lateCull ? *lateCount : k->m_NbInstances;
@@ -411,6 +412,10 @@ static void instance_cull_mt(const OrcGPUCullingPassConstants* k, int lateCull,
     const uint32_t* ids;
     if (lateCull) {
         uint64_t launched = (uint64_t)lateDispatchArgsX * ORC_NUM_THREADS_PER_WAVE;   /* Q1 */
+        if (shardLate) {   /* the same rule on the rank-major concatenation of all shards' late lists */
+            uint64_t all = (((uint64_t)shardLate[1] + 63u) / 64u) * ORC_NUM_THREADS_PER_WAVE;
+            launched = all > shardLate[0] ? all - shardLate[0] : 0u;
+        }
         nThreads = (uint32_t)(launched < nbInstances ? launched : nbInstances);
         ids = lateIds;
     } else {
@@ -472,7 +477,7 @@ void orc_instance_cull(const OrcGPUCullingPassConstants* k, int lateCull,
                        uint32_t maxGroups, uint32_t* validRecords)
 {
     instance_cull_mt(k, lateCull, instances, primitiveIds, meshData, hzb, records, dispatchArgs,
-                     lateCount, lateIds, lateDispatchArgsX, maxGroups, validRecords, 1);
+                     lateCount, lateIds, lateDispatchArgsX, maxGroups, validRecords, 1, NULL);
 }
 
 /* gpuculling.hlsl:182-195 (Q1: 64, not kNumThreadsPerWave) */
@@ -701,8 +706,10 @@ static void run_pass(OrcFrameDesc* d, OrcFrameOut* o, int slot, int late, int al
     k.m_ForcedMeshLOD = d->forceMeshLOD >= 0 ? (uint32_t)d->forceMeshLOD : ORC_INVALID_LOD;
     k.m_MeshLODTarget = (2.0f / d->viewToClip.m[1][1]) * (1.0f / (float)d->renderHeight);
 
+    const uint32_t shard[2] = { d->shardLateBase[li], d->shardLateTotal[li] };
     instance_cull_mt(&k, late, d->instances, ids, d->meshData, hzb, o->records[slot], o->dispatchArgs[slot],
-                     &o->lateCount[li], o->lateIds[li], o->lateArgs[li][0], d->maxGroups, &o->validRecords[slot], d->threads);
+                     &o->lateCount[li], o->lateIds[li], o->lateArgs[li][0], d->maxGroups, &o->validRecords[slot], d->threads,
+                     (late && d->shardLate) ? shard : NULL);
     if (!late && occlusion)
         orc_build_late_args(o->lateCount[li], o->lateArgs[li]);           /* :377-389 */
 

@@ -223,6 +223,12 @@ typedef struct {
     uint16_t* hzbTexels; uint32_t hzbW, hzbH, hzbMips; uint64_t hzbMipOffset[ORC_MAX_MIPS];
     const float* depth; uint32_t depthW, depthH;
     uint32_t threads;           /* >1: static contiguous partition, outputs concatenated in order */
+    /* Multi-GPU checker only (not in the reference): this frame culls ONE SHARD of the instance list.
+     * The late dispatch size rule (Q1) then applies to the whole scene's late list, of which this
+     * shard's entries start at shardLateBase[bucket] (bucket 0 opaque, 1 alpha mask):
+     * threads = clamp(ceil(shardLateTotal/64)*32 - shardLateBase, 0, own late count). */
+    uint32_t shardLate;
+    uint32_t shardLateBase[2], shardLateTotal[2];
 } OrcFrameDesc;
 
 /* Outputs per pass slot: 0 early-opaque, 1 late-opaque, 2 early-alphamask, 3 late-alphamask. */

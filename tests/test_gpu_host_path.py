@@ -148,7 +148,8 @@ def test_headline_config_subsample_spot_check(oracle):
 
 def test_bench_rccl_gather_path_single_rank():
     """bench.py end to end on a small unique-meshlet config with the RCCL gather forced on a 1-rank
-    group: exercises device-pointer wrapping, the count exchange and the variable-length all_gather."""
+    group: exercises device-pointer wrapping, the pack / all_gather_into_tensor / unpack pipeline on two
+    streams with double buffering, and checks the gathered whole-scene lists against the local ones."""
     import json
     import os
     import subprocess

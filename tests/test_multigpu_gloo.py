@@ -1,7 +1,10 @@
 """The N > 1 path on CPU: world_size-2 (and 3) gloo processes shard the instance list by contiguous
-ranges, each cull their shard (with the oracle standing in for the GPU), and the variable-length
-all-gather + group rebase of toyrenderer_amd/gather.py must reproduce the single-process lists bit for
-bit (rank-major concatenation == single-GPU canonical order)."""
+ranges, each cull their shard (with the oracle standing in for the GPU), and the shard-slot exchange of
+toyrenderer_amd/gather.py (one equal-size all-gather of compact records + lane masks, rank-major
+concatenation, list rebuild) must reproduce the single-process records and visible lists bit for bit
+(rank-major concatenation == single-GPU canonical order).  The host logic under test is
+gather.ShardExchange; the data movers are the numpy statement of the protocol (tests/exchange_ref.py),
+which the -m gpu tests hold the HIP kernels to."""
 import os
 import sys
 
@@ -12,8 +15,9 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if ROOT not in sys.path:
-    sys.path.insert(0, ROOT)
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
 
 
 def _worker(rank, world, port, out_dir):
@@ -23,43 +27,52 @@ def _worker(rank, world, port, out_dir):
     try:
         from oracle import pyoracle
         from toyrenderer_amd import gather, synth
-        spec = synth.SceneSpec(num_meshes=30, num_instances=257, meshlets_lod0=50, jitter_meshlets=True, max_lods=4, seed=99)
+        from exchange_ref import NumpyShardExchange
+        spec = synth.SceneSpec(num_meshes=30, num_instances=3001, meshlets_lod0=50, jitter_meshlets=True, max_lods=4, seed=99)
         scene = synth.make_scene(spec)
         view = synth.make_view(eye=(0.3, 0.1, 0.4), yaw=0.02, prev_eye=(0, 0, 0), prev_yaw=0.0, render=(640, 360))
         d_prev = synth.gen_depth(view, 50, seed=5, scale=3.0)
         d_cur = synth.gen_depth(view, 40, seed=6, scale=3.0)
 
-        def run(ids):
+        def run(ids, shard_late=None):
             hzb = pyoracle.HzbTexture(*view.hzb_dims)
             hzb.build_from_depth(d_prev)
             sc = dict(scene.as_oracle()); sc["opaqueIds"] = ids; sc["alphaMaskIds"] = np.zeros(0, np.uint32)
-            return pyoracle.frame(sc, view.as_dict(), hzb, d_cur, cullingFlags=7, maxGroups=1 << 20, record_capacity=4096)
+            return pyoracle.frame(sc, view.as_dict(), hzb, d_cur, cullingFlags=7, maxGroups=1 << 20, record_capacity=1 << 15, shard_late=shard_late)
 
         all_ids = np.arange(spec.num_instances, dtype=np.uint32)
         i0, i1 = gather.shard_range(spec.num_instances, rank, world)
-        local = run(all_ids[i0:i1])
+        # the in-frame exchange of the late-list lengths (gather.py docstring): early phase -> all-gather of
+        # the late counts -> late phase with {entries of the lower ranks, of all ranks}
+        mine = torch.tensor([int(run(all_ids[i0:i1]).lateCount[0])], dtype=torch.int32)
+        counts = torch.zeros(world, dtype=torch.int32)
+        dist.all_gather_into_tensor(counts, mine)
+        local = run(all_ids[i0:i1], shard_late=(gather.shard_late_info(counts.tolist(), rank), (0, 0)))
         full = run(all_ids) if rank == 0 else None
+        if rank == 0:
+            assert int(counts.sum()) == int(full.lateCount[0]) > 64, "late list too short for the dispatch-size rule (Q1) to matter"
+            assert len(full.records[1]) > 0
 
-        for slot in (0, 1):
-            rec = torch.from_numpy(local.records[slot].view(np.uint32).astype(np.int64).astype(np.int32).reshape(-1).copy())
-            lst = torch.from_numpy(local.visibleList[slot].astype(np.int64).astype(np.int32).copy())
-            # pad like the fixed-capacity device buffers
-            rec_buf = torch.zeros(3 * 4096, dtype=torch.int32); rec_buf[:rec.numel()] = rec
-            lst_buf = torch.zeros(32 * 4096, dtype=torch.int32); lst_buf[:lst.numel()] = lst
-            counts = gather.exchange_counts(dist, torch, torch.tensor([len(local.records[slot]), len(local.visibleList[slot])], dtype=torch.int32), world)
-            G, V = counts[:, 0], counts[:, 1]
-            out_list = torch.zeros(32 * 4096 * world, dtype=torch.int32)
-            out_rec = torch.zeros(3 * 4096 * world, dtype=torch.int32)
-
-            def rebase(add, lst_buf=lst_buf, n=int(V[rank])):
-                lst_buf[:n] += add
-            g_tot, v_tot = gather.gather_slot(dist, rank, world, out_list, out_rec, lst_buf, rec_buf, G, V, rebase, uneven_ok=False)
-            if rank == 0:
-                got_rec = out_rec[:3 * g_tot].numpy().view(np.uint32).reshape(-1, 3)
-                got_lst = out_list[:v_tot].numpy().view(np.uint32)
-                assert np.array_equal(got_rec, full.records[slot].view(np.uint32).reshape(-1, 3)), f"slot {slot}: records"
-                assert np.array_equal(got_lst, full.visibleList[slot]), f"slot {slot}: visible list"
-                assert g_tot == len(full.records[slot]) and v_tot == int(full.drawArgs[slot][0])
+        md = scene.as_oracle()["meshData"]
+        inst = scene.as_oracle()["instances"]
+        cap_local = gather.shard_group_capacity(md["m_MeshLODDatas"]["m_NumMeshlets"], inst["m_MeshDataIdx"][all_ids[i0:i1]])
+        slot_groups = gather.agree_slot_groups(dist, torch, cap_local)
+        assert slot_groups >= cap_local
+        ex = NumpyShardExchange(dist, torch, world, rank, slot_groups, pass_slots=(0, 1))
+        for frame in range(3):                      # three frames: both buffer indices, and reuse of one
+            ex.set_local({s: (local.records[s].view(np.uint32).reshape(-1, 3), local.visMask[s], int(local.drawArgs[s][0])) for s in (0, 1)})
+            ex.run()
+            for slot in (0, 1):
+                got_rec, got_lst = ex.results(slot)
+                if rank == 0:
+                    assert np.array_equal(got_rec, full.records[slot].view(np.uint32).reshape(-1, 3)), f"slot {slot}: records"
+                    assert np.array_equal(got_lst, full.visibleList[slot]), f"slot {slot}: visible list"
+                    assert len(got_lst) == int(full.drawArgs[slot][0])
+        # every rank holds the same whole-scene result
+        chk = torch.tensor([int(np.bitwise_xor.reduce(ex.results(0)[1])) & 0x7FFFFFFF, len(ex.results(1)[0])], dtype=torch.int64)
+        parts = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(parts, chk)
+        assert all(torch.equal(p_, parts[0]) for p_ in parts)
         if rank == 0:
             assert full.dispatchArgs[0][0] > 0 and full.drawArgs[0][0] > 0
             open(os.path.join(out_dir, f"ok_{world}"), "w").write("ok")
@@ -83,3 +96,38 @@ def test_shard_ranges_partition_the_list():
             assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
             sizes = [b - a for a, b in r]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_slot_protocol_numpy_roundtrip_and_overflow():
+    """pack -> (concatenated slots) -> unpack on one process: ordering, absent pass slots, overflow flags."""
+    from exchange_ref import expand_masks_np, pack_shard_np, unpack_shards_np
+    from toyrenderer_amd.gather import slot_words
+    rng = np.random.default_rng(3)
+    world, S = 3, 40
+    shards, slots = [], []
+    for p in range(world):
+        loc = {}
+        for s in (0, 1, 3):
+            g = int(rng.integers(0, 12))
+            rec = rng.integers(0, 2 ** 32, (g, 3), dtype=np.uint64).astype(np.uint32)
+            m = rng.integers(0, 2 ** 32, g, dtype=np.uint64).astype(np.uint32)
+            loc[s] = (rec, m, int(sum(bin(int(x)).count("1") for x in m)))
+        shards.append(loc)
+        slots.append(pack_shard_np(loc, S))
+        assert len(slots[-1]) == slot_words(S) and slots[-1][8] == 0
+    out = unpack_shards_np(np.concatenate(slots), world, S, (0, 1, 3), world * S)
+    for s in (0, 1, 3):
+        rec = np.concatenate([sh[s][0] for sh in shards])
+        m = np.concatenate([sh[s][1] for sh in shards])
+        assert np.array_equal(out[s]["records"], rec) and np.array_equal(out[s]["masks"], m)
+        assert np.array_equal(out[s]["list"], expand_masks_np(m)) and out[s]["status"] == 0
+        assert out[s]["V"] == sum(sh[s][2] for sh in shards)
+    lst = expand_masks_np(np.array([0b101, 0, 1 << 31], np.uint32))
+    assert lst.tolist() == [0, 2, (2 << 5) | 31]
+    # a shard that emits more groups than the slot holds is flagged, never silently truncated
+    big = {0: (np.zeros((30, 3), np.uint32), np.ones(30, np.uint32), 30), 1: (np.zeros((20, 3), np.uint32), np.ones(20, np.uint32), 20)}
+    sl = pack_shard_np(big, S)
+    assert sl[8] == 1 and sl[0] == 30 and sl[2] == 10
+    assert unpack_shards_np(sl, 1, S, (0, 1), S)[0]["status"] & 1
+    # whole-scene capacity too small
+    assert unpack_shards_np(np.concatenate(slots), world, S, (0, 1, 3), 5)[0]["status"] & 2

@@ -29,6 +29,26 @@ using namespace interop;
 
 RenderGraph::ResourceHandle g_DepthStencilBufferRDGTextureHandle;            // BasePassRenderers.cpp:15
 
+// Multi-GPU hook (not in the reference): see trhost.h, trhost_set_shard_late_exchange.
+namespace
+{
+struct { ShardLateFn fn = nullptr; void* user = nullptr; } g_ShardLateExchange;
+struct ShardLateCall { nvrhi::BufferHandle info; void* lateCount = nullptr; void* infoPtr = nullptr; int bucket = 0; };
+ShardLateCall g_ShardLateCalls[2];                                           // opaque, alpha mask
+
+void ShardLateTrampoline(void* user, void* hipStream)
+{
+    const ShardLateCall* c = (const ShardLateCall*)user;
+    if (g_ShardLateExchange.fn) g_ShardLateExchange.fn(g_ShardLateExchange.user, hipStream, c->lateCount, c->infoPtr, c->bucket);
+}
+}
+
+void SetShardLateExchange(ShardLateFn fn, void* user)
+{
+    g_ShardLateExchange.fn = fn;
+    g_ShardLateExchange.user = user;
+}
+
 // ---------------------------------------------------------------------------------------------------
 class UpdateInstanceConstsRenderer : public IRenderer
 {
@@ -278,6 +298,23 @@ public:
                 g_Graphic.AddComputePass(computePassParams);
             }
         } else if (m_bDoOcclusionCulling) {                                   // :392-402
+            if (g_ShardLateExchange.fn) {
+                // multi-GPU: the late dispatch size rule sees the whole scene's late list (trhost.h)
+                ShardLateCall& call = g_ShardLateCalls[bAlphaMaskPrimitives ? 1 : 0];
+                if (!call.info) {
+                    nvrhi::BufferDesc desc;
+                    desc.byteSize = 2 * sizeof(uint32_t);
+                    desc.structStride = sizeof(uint32_t);
+                    desc.canHaveUAVs = true;
+                    desc.debugName = bAlphaMaskPrimitives ? "ShardLateInfoAlphaMask" : "ShardLateInfoOpaque";
+                    call.info = g_Graphic.m_NVRHIDevice->createBuffer(desc);
+                }
+                call.lateCount = trhip_buffer_device_ptr(lateCullInstanceCountBuffer->native());
+                call.infoPtr = trhip_buffer_device_ptr(call.info->native());
+                call.bucket = bAlphaMaskPrimitives ? 1 : 0;
+                commandList->hostCallback(&ShardLateTrampoline, &call);
+                bindingSetDesc.bindings.push_back(nvrhi::BindingSetItem::StructuredBuffer_SRV(4, call.info));
+            }
             Graphic::ComputePassParams computePassParams;
             computePassParams.m_CommandList = commandList;
             computePassParams.m_ShaderName = shaderName;
@@ -510,4 +547,6 @@ void ReleaseVisibilityPassBuffers()
     for (auto& o : r->m_Outputs) o = BasePassRenderer::PassOutputs{};
     r->m_LastLateCullInstanceCountBuffer = nullptr;
     r->m_LastLateCullDispatchIndirectArgsBuffer = nullptr;
+    for (ShardLateCall& c : g_ShardLateCalls) c = ShardLateCall{};
+    SetShardLateExchange(nullptr, nullptr);
 }

@@ -19,3 +19,8 @@ struct VisibilityPassBuffers
 // slot: 0 early-opaque, 1 late-opaque, 2 early-alpha-mask, 3 late-alpha-mask
 bool GetVisibilityPassBuffers(uint32_t slot, VisibilityPassBuffers* out);
 void ReleaseVisibilityPassBuffers();
+
+// Multi-GPU (instance list sharded over ranks; trhost.h trhost_set_shard_late_exchange): called while
+// the frame is submitted, before each late instance cull.
+using ShardLateFn = void (*)(void* user, void* hipStream, void* lateCount, void* shardInfo, int bucket);
+void SetShardLateExchange(ShardLateFn fn, void* user);

@@ -291,6 +291,8 @@ public:
         keep(dst); keep(src);
         throwIfFailed(trhip_cmd_copy_buffer(m_Native, dst->native(), dstOff, src->native(), srcOff, bytes), "ICommandList::copyBuffer");
     }
+    // Multi-GPU hook (trhip_cmd_host_callback): not part of NVRHI.
+    void hostCallback(trhip_host_fn fn, void* user) { throwIfFailed(trhip_cmd_host_callback(m_Native, fn, user), "ICommandList::hostCallback"); }
     void copyTexture(ITexture* dst, ITexture* src) { keep(dst); keep(src); throwIfFailed(trhip_cmd_copy_texture(m_Native, dst->native(), src->native()), "ICommandList::copyTexture"); }
 
     void setComputeState(const ComputeState& s)

@@ -178,6 +178,11 @@ int trhost_instance_buffer(void** buffer)
     return guarded([&] { *buffer = g_Scene->m_InstanceConstsBuffer ? (void*)g_Scene->m_InstanceConstsBuffer->native() : nullptr; });
 }
 
+int trhost_set_shard_late_exchange(trhost_shard_late_fn fn, void* user)
+{
+    return guarded([&] { SetShardLateExchange(fn, user); });
+}
+
 int trhost_render_graph_stats(uint32_t* num_heaps, uint64_t* bytes_reserved, uint64_t* bytes_used, uint32_t* num_passes)
 {
     return guarded([&] {

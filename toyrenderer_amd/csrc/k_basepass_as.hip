@@ -28,7 +28,9 @@
 //     cone test's ALU work;
 //   * the 64-bit ballot is the two groups' visibility masks (WaveActiveCountBits/WavePrefix-
 //     CountBits :116-120); masks and the batch popcount are written once per batch.
+#include <algorithm>
 #include <cstdlib>
+#include <string>
 #include <type_traits>
 
 #include "cull_math.hip.h"
@@ -393,13 +395,168 @@ __global__ __launch_bounds__(kBlock) void visExpandKernel(MeshletCullArgs a)
     }
 }
 
-// Multi-GPU: a rank's list entries address its own records; before the all-gather each rank adds
-// the number of groups of the lower ranks so that (g << 5) | lane indexes the rank-major
-// concatenation of the record arrays (= the single-GPU canonical order).
-__global__ __launch_bounds__(256) void rebaseVisibleListKernel(uint32_t* list, const uint32_t* drawArgs, uint32_t capacity, uint32_t add)
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU exchange (not in the reference: single GPU, GraphicRHI.cpp:165).
+// A rank ships its pass slots in COMPACT form -- the 12-byte record and the 4-byte lane mask of every
+// group, i.e. 1 bit per tested meshlet instead of 4 bytes per visible meshlet -- inside one
+// fixed-capacity "shard slot", so that the frame needs ONE equal-size all-gather and no host
+// read-back.  Every rank then concatenates the slots rank-major (device-side offsets from the slot
+// headers) and rebuilds the whole-scene ordered visible list with the same count/scan/expand kernels
+// the single-GPU path uses: the result is bit-identical to a single-GPU frame.
+//
+// Shard slot (u32 words), S = slotGroups:
+//   [0..15]        header: {G_s, V_s} for pass slot s = 0..3 at words 2s, 2s+1; word 8 = overflow flag,
+//                  word 9 = the rank dropped groups at its record capacity (Q2)
+//   [16, 16+3S)    records of pass slot 0, then 1, ... back to back (3 words each)
+//   [16+3S, 16+4S) lane masks in the same order
+constexpr uint32_t kMaxPassSlots = 4;
+constexpr uint32_t kSlotHeaderWords = 16;
+constexpr uint32_t kMaxRanks = 64;
+
+struct ShardPackArgs
 {
-    const uint32_t n = drawArgs[0] < capacity ? drawArgs[0] : capacity;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) list[i] += add;
+    const uint32_t* records[kMaxPassSlots];
+    const uint32_t* masks[kMaxPassSlots];
+    const uint32_t* dispatchArgs[kMaxPassSlots];
+    const uint32_t* drawArgs[kMaxPassSlots];
+    uint32_t argsWords[kMaxPassSlots];
+    uint32_t recordCapacity[kMaxPassSlots];
+    uint32_t* slot;
+    uint32_t slotGroups;
+};
+
+__global__ __launch_bounds__(256) void shardPackKernel(ShardPackArgs a)
+{
+    uint32_t G[kMaxPassSlots], start[kMaxPassSlots + 1];
+    uint32_t overflow = 0, dropped = 0;
+    start[0] = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < kMaxPassSlots; ++s) {
+        uint32_t g = 0;
+        if (a.dispatchArgs[s]) {                                                    // same rule as groupCount()
+            g = a.dispatchArgs[s][0];
+            if (a.argsWords[s] > 3 && a.dispatchArgs[s][3] < g) g = a.dispatchArgs[s][3];
+            g = g < a.recordCapacity[s] ? g : a.recordCapacity[s];
+            if (g != a.dispatchArgs[s][0]) dropped = 1;                             // the counter counts dropped groups too (Q2)
+        }
+        if (start[s] + g > a.slotGroups) { g = a.slotGroups - start[s]; overflow = 1; }
+        G[s] = g;
+        start[s + 1] = start[s] + g;
+    }
+    const uint32_t total = start[kMaxPassSlots];
+    uint32_t* recOut = a.slot + kSlotHeaderWords;
+    uint32_t* maskOut = recOut + 3ull * a.slotGroups;
+    const uint32_t stride = gridDim.x * 256u;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < 3u * total; i += stride) {   // records, word by word (coalesced)
+        const uint32_t g = i / 3u;
+        uint32_t s = 0;
+#pragma unroll
+        for (uint32_t q = 1; q < kMaxPassSlots; ++q) s += g >= start[q] ? 1u : 0u;
+        recOut[i] = a.records[s][i - 3u * start[s]];
+    }
+    for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < total; g += stride) {
+        uint32_t s = 0;
+#pragma unroll
+        for (uint32_t q = 1; q < kMaxPassSlots; ++q) s += g >= start[q] ? 1u : 0u;
+        maskOut[g] = a.masks[s][g - start[s]];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < kSlotHeaderWords) {
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t s = 0; s < kMaxPassSlots; ++s) {
+            if (threadIdx.x == 2 * s) v = G[s];
+            if (threadIdx.x == 2 * s + 1) v = a.drawArgs[s] ? a.drawArgs[s][0] : 0u;
+        }
+        if (threadIdx.x == 8) v = overflow;
+        if (threadIdx.x == 9) v = dropped;
+        a.slot[threadIdx.x] = v;
+    }
+}
+
+struct ShardUnpackArgs
+{
+    const uint32_t* recv;                  // world x (16 + 4 * slotGroups) words
+    uint32_t world, slotGroups;
+    uint32_t* records[kMaxPassSlots];      // whole-scene outputs per pass slot (nullptr = not gathered)
+    uint32_t* masks[kMaxPassSlots];
+    uint32_t* args[kMaxPassSlots];         // 8 words: {G,1,1,G} dispatch args, {V,1,1} draw args, status
+    uint32_t capacity[kMaxPassSlots];      // groups
+};
+
+// Rank-major concatenation.  Segment k = (rank p, pass slot s, records | masks); every block derives the
+// segment table from the slot headers (world <= 64), then the grid copies the words of all segments.
+__global__ __launch_bounds__(256) void shardConcatKernel(ShardUnpackArgs a)
+{
+    __shared__ uint32_t s_G[kMaxRanks][kMaxPassSlots];
+    __shared__ uint32_t s_start[2 * kMaxPassSlots * kMaxRanks + 1];
+    __shared__ uint32_t s_src[2 * kMaxPassSlots * kMaxRanks];
+    __shared__ uint32_t s_dst[2 * kMaxPassSlots * kMaxRanks];
+    const uint32_t slotWords = kSlotHeaderWords + 4u * a.slotGroups;
+    const uint32_t tid = threadIdx.x;
+    if (tid < a.world * kMaxPassSlots) {
+        const uint32_t p = tid / kMaxPassSlots, s = tid % kMaxPassSlots;
+        s_G[p][s] = a.records[s] ? a.recv[(uint64_t)p * slotWords + 2u * s] : 0u;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t status = 0, run = 0, k = 0;
+        uint32_t off[kMaxPassSlots] = {};
+        for (uint32_t p = 0; p < a.world; ++p) {
+            if (a.recv[(uint64_t)p * slotWords + 8u]) status |= 1u;                // that rank's slot overflowed
+            if (a.recv[(uint64_t)p * slotWords + 9u]) status |= 8u;                // that rank dropped groups (Q2)
+            uint32_t inSlot = 0;
+            for (uint32_t s = 0; s < kMaxPassSlots; ++s) {
+                uint32_t g = s_G[p][s];
+                const uint32_t srcG = inSlot;
+                inSlot += g;
+                if (inSlot > a.slotGroups) { status |= 4u; g = 0; }                // corrupt header: copy nothing
+                if (off[s] + g > a.capacity[s]) { g = a.capacity[s] - off[s]; status |= 2u; }
+                const uint32_t base = p * slotWords + kSlotHeaderWords;            // < 2^32 words (checked on the host)
+                s_start[k] = run; s_src[k] = base + 3u * srcG; s_dst[k] = 3u * off[s]; run += 3u * g; ++k;
+                s_start[k] = run; s_src[k] = base + 3u * a.slotGroups + srcG; s_dst[k] = off[s]; run += g; ++k;
+                off[s] += g;
+            }
+        }
+        s_start[k] = run;
+        if (blockIdx.x == 0)
+            for (uint32_t s = 0; s < kMaxPassSlots; ++s)
+                if (a.args[s]) {
+                    a.args[s][0] = off[s]; a.args[s][1] = 1; a.args[s][2] = 1; a.args[s][3] = off[s];
+                    a.args[s][7] = status;
+                }
+    }
+    __syncthreads();
+    const uint32_t numSeg = 2u * kMaxPassSlots * a.world;
+    const uint32_t total = s_start[numSeg];
+    for (uint32_t i = blockIdx.x * 256u + tid; i < total; i += gridDim.x * 256u) {
+        uint32_t lo = 0, hi = numSeg;                                              // last k with s_start[k] <= i
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_start[mid] <= i) lo = mid; else hi = mid;
+        }
+        const uint32_t s = (lo >> 1) % kMaxPassSlots;
+        uint32_t* dst = (lo & 1u) ? a.masks[s] : a.records[s];
+        dst[s_dst[lo] + (i - s_start[lo])] = a.recv[(uint64_t)s_src[lo] + (i - s_start[lo])];
+    }
+}
+
+// Launches the ordered-list build (count -> scan -> expand) over a mask array.
+void emitListBuild(const trhip::DispatchCtx& ctx, const MeshletCullArgs& a, const char* prefix)
+{
+    const uint32_t needBlocks = (a.maxBatches + kWaves - 1) / kWaves;
+    uint32_t gridSmall = ctx.computeUnits() * 8u;      // count / expand: light kernels, one wave per 64 groups
+    if (gridSmall > needBlocks) gridSmall = needBlocks;
+    if (gridSmall == 0) gridSmall = 1;
+    const std::string p = prefix;
+    ctx.emit((p + "count").c_str(), [a, gridSmall](hipStream_t s) {
+        hipLaunchKernelGGL(visCountKernel, dim3(gridSmall), dim3(kBlock), 0, s, a);
+        return trhip::launchStatus("visCountKernel"); });
+    ctx.emit((p + "scan").c_str(), [a](hipStream_t s) {
+        hipLaunchKernelGGL(visScanKernel, dim3(1), dim3(1024), 0, s, a);
+        return trhip::launchStatus("visScanKernel"); });
+    ctx.emit((p + "expand").c_str(), [a, gridSmall](hipStream_t s) {
+        hipLaunchKernelGGL(visExpandKernel, dim3(gridSmall), dim3(kBlock), 0, s, a);
+        return trhip::launchStatus("visExpandKernel"); });
 }
 
 template <bool F, bool O, bool C>
@@ -494,79 +651,113 @@ int recordASMain(trhip::DispatchCtx& ctx)
         default: launchCull<true, true, true>(a, grid, s); break;
         }
         return trhip::launchStatus("meshletCullKernel"); });
-    uint32_t gridSmall = ctx.computeUnits() * 8u;      // count / expand: light kernels, one wave per 64 groups
-    if (gridSmall > needBlocks) gridSmall = needBlocks;
-    if (gridSmall == 0) gridSmall = 1;
-    ctx.emit("count", [a, gridSmall](hipStream_t s) {
-        hipLaunchKernelGGL(visCountKernel, dim3(gridSmall), dim3(kBlock), 0, s, a);
-        return trhip::launchStatus("visCountKernel"); });
-    ctx.emit("scan", [a](hipStream_t s) {
-        hipLaunchKernelGGL(visScanKernel, dim3(1), dim3(1024), 0, s, a);
-        return trhip::launchStatus("visScanKernel"); });
-    ctx.emit("expand", [a, gridSmall](hipStream_t s) {
-        hipLaunchKernelGGL(visExpandKernel, dim3(gridSmall), dim3(kBlock), 0, s, a);
-        return trhip::launchStatus("visExpandKernel"); });
+    emitListBuild(ctx, a, "");
     return TRHIP_OK;
 }
 
-// Multi-GPU: {G0, V0, G1, V1} of the two opaque pass slots in one 16-byte buffer (one launch instead of
-// several host-side tensor operations); G = min(X, validRecords).
-__global__ void packCountsKernel(const uint32_t* args0, const uint32_t* draw0, const uint32_t* args1, const uint32_t* draw1,
-                                 uint32_t words0, uint32_t words1, uint32_t* out)
+// "visibility_CS_PackShard": pass slot s binds t(4s) records, t(4s+1) visMask, t(4s+2) dispatch args,
+// t(4s+3) draw args (all four or none); u0 = the shard slot; push constants {slotGroups}.
+int recordPackShard(trhip::DispatchCtx& ctx)
 {
-    if (threadIdx.x != 0) return;
-    uint32_t g0 = args0 ? args0[0] : 0u, g1 = args1 ? args1[0] : 0u;
-    if (args0 && words0 > 3 && args0[3] < g0) g0 = args0[3];
-    if (args1 && words1 > 3 && args1[3] < g1) g1 = args1[3];
-    out[0] = g0; out[1] = draw0 ? draw0[0] : 0u;
-    out[2] = g1; out[3] = draw1 ? draw1[0] : 0u;
-}
-
-int recordPackCounts(trhip::DispatchCtx& ctx)
-{
-    trhip_buffer_t* a0 = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 0);
-    trhip_buffer_t* d0 = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 1);
-    trhip_buffer_t* a1 = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 2);
-    trhip_buffer_t* d1 = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 3);
-    trhip_buffer_t* out = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 0);
-    TRHIP_REQUIRE(out && out->byteSize >= 16, "%s: needs UAV u0 (16 bytes)", ctx.shaderName);
-    TRHIP_REQUIRE((!a0 || a0->byteSize >= 12) && (!a1 || a1->byteSize >= 12) && (!d0 || d0->byteSize >= 12) && (!d1 || d1->byteSize >= 12),
-                  "%s: argument buffers smaller than 12 bytes", ctx.shaderName);
-    const uint32_t* pa0 = a0 ? (const uint32_t*)a0->ptr : nullptr;
-    const uint32_t* pd0 = d0 ? (const uint32_t*)d0->ptr : nullptr;
-    const uint32_t* pa1 = a1 ? (const uint32_t*)a1->ptr : nullptr;
-    const uint32_t* pd1 = d1 ? (const uint32_t*)d1->ptr : nullptr;
-    const uint32_t w0 = a0 && a0->byteSize >= 16 ? 4u : 3u, w1 = a1 && a1->byteSize >= 16 ? 4u : 3u;
-    uint32_t* po = (uint32_t*)out->ptr;
-    ctx.emit("main", [=](hipStream_t s) {
-        hipLaunchKernelGGL(packCountsKernel, dim3(1), dim3(64), 0, s, pa0, pd0, pa1, pd1, w0, w1, po);
-        return trhip::launchStatus("packCountsKernel"); });
-    return TRHIP_OK;
-}
-
-int recordRebase(trhip::DispatchCtx& ctx)
-{
-    const uint32_t* groupBase = (const uint32_t*)ctx.constants(0, 4);
-    trhip_buffer_t* list = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 0);
-    trhip_buffer_t* drawArgs = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 0);
-    TRHIP_REQUIRE(groupBase && list && drawArgs, "%s: needs push constant {groupBase}, UAV u0 (visible list), SRV t0 (draw args)", ctx.shaderName);
-    TRHIP_REQUIRE(drawArgs->byteSize >= 12, "%s: draw args smaller than 12 bytes", ctx.shaderName);
-    TRHIP_REQUIRE(*groupBase < (1u << 27), "%s: group base %u does not fit (g << 5)", ctx.shaderName, *groupBase);
-    uint32_t* lp = (uint32_t*)list->ptr;
-    const uint32_t* dp = (const uint32_t*)drawArgs->ptr;
-    const uint64_t cap64 = list->byteSize / 4;
-    const uint32_t cap = cap64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap64;
-    const uint32_t add = *groupBase << 5;
+    const uint32_t* push = (const uint32_t*)ctx.constants(0, 4);
+    trhip_buffer_t* slot = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 0);
+    TRHIP_REQUIRE(push && slot, "%s: needs push constants {slotGroups} and UAV u0 (shard slot)", ctx.shaderName);
+    ShardPackArgs a;
+    memset(&a, 0, sizeof a);
+    a.slotGroups = push[0];
+    TRHIP_REQUIRE(slot->byteSize >= ((uint64_t)kSlotHeaderWords + 4ull * a.slotGroups) * 4, "%s: shard slot buffer smaller than 16 + 4 * %u words", ctx.shaderName, a.slotGroups);
+    a.slot = (uint32_t*)slot->ptr;
+    for (uint32_t s = 0; s < kMaxPassSlots; ++s) {
+        trhip_buffer_t* rec = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 4 * s);
+        trhip_buffer_t* mask = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 4 * s + 1);
+        trhip_buffer_t* args = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 4 * s + 2);
+        trhip_buffer_t* draw = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 4 * s + 3);
+        if (!rec && !mask && !args && !draw) continue;
+        TRHIP_REQUIRE(rec && mask && args && draw, "%s: pass slot %u needs t%u..t%u (records, visMask, dispatch args, draw args)", ctx.shaderName, s, 4 * s, 4 * s + 3);
+        TRHIP_REQUIRE(args->byteSize >= 12 && draw->byteSize >= 12, "%s: argument buffers smaller than 12 bytes", ctx.shaderName);
+        const uint64_t cap = std::min<uint64_t>(rec->byteSize / sizeof(MeshletAmplificationData), mask->byteSize / 4);
+        a.records[s] = (const uint32_t*)rec->ptr;
+        a.masks[s] = (const uint32_t*)mask->ptr;
+        a.dispatchArgs[s] = (const uint32_t*)args->ptr;
+        a.drawArgs[s] = (const uint32_t*)draw->ptr;
+        a.argsWords[s] = args->byteSize >= 16 ? 4u : 3u;
+        a.recordCapacity[s] = cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;
+    }
     uint32_t grid = ctx.computeUnits() * 4u;
+    const uint32_t need = (3u * a.slotGroups + 255u) / 256u;
+    if (grid > need) grid = need;
     if (grid == 0) grid = 1;
-    ctx.emit("main", [=](hipStream_t s) {
-        hipLaunchKernelGGL(rebaseVisibleListKernel, dim3(grid), dim3(256), 0, s, lp, dp, cap, add);
-        return trhip::launchStatus("rebaseVisibleListKernel"); });
+    ctx.emit("main", [a, grid](hipStream_t s) {
+        hipLaunchKernelGGL(shardPackKernel, dim3(grid), dim3(256), 0, s, a);
+        return trhip::launchStatus("shardPackKernel"); });
     return TRHIP_OK;
 }
 
-trhip::ShaderRegistrar rr("visibility_CS_RebaseVisibleList", recordRebase, 0);
-trhip::ShaderRegistrar rp("visibility_CS_PackCounts", recordPackCounts, 0);
+// "visibility_CS_UnpackShards": t0 = the gathered slots (world x slot words); pass slot s binds
+// u(4s) records, u(4s+1) masks, u(4s+2) visible list, u(4s+3) args (8 words: {G,1,1,G}, {V,1,1}, status);
+// push constants {world, slotGroups}.
+int recordUnpackShards(trhip::DispatchCtx& ctx)
+{
+    const uint32_t* push = (const uint32_t*)ctx.constants(0, 8);
+    trhip_buffer_t* recv = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 0);
+    TRHIP_REQUIRE(push && recv, "%s: needs push constants {world, slotGroups} and SRV t0 (gathered slots)", ctx.shaderName);
+    ShardUnpackArgs a;
+    memset(&a, 0, sizeof a);
+    a.world = push[0];
+    a.slotGroups = push[1];
+    TRHIP_REQUIRE(a.world >= 1 && a.world <= kMaxRanks, "%s: world size %u outside [1, %u]", ctx.shaderName, a.world, kMaxRanks);
+    const uint64_t words = (uint64_t)a.world * (kSlotHeaderWords + 4ull * a.slotGroups);
+    TRHIP_REQUIRE(words < (1ull << 32), "%s: %u slots of %u groups exceed 2^32 words", ctx.shaderName, a.world, a.slotGroups);
+    TRHIP_REQUIRE(recv->byteSize >= words * 4, "%s: gathered buffer smaller than world x slot", ctx.shaderName);
+    a.recv = (const uint32_t*)recv->ptr;
+    MeshletCullArgs lists[kMaxPassSlots];
+    uint64_t copyWords = 0;
+    for (uint32_t s = 0; s < kMaxPassSlots; ++s) {
+        trhip_buffer_t* rec = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 4 * s);
+        trhip_buffer_t* mask = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 4 * s + 1);
+        trhip_buffer_t* list = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 4 * s + 2);
+        trhip_buffer_t* args = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 4 * s + 3);
+        if (!rec && !mask && !list && !args) continue;
+        TRHIP_REQUIRE(rec && mask && list && args, "%s: pass slot %u needs u%u..u%u (records, masks, visible list, args)", ctx.shaderName, s, 4 * s, 4 * s + 3);
+        TRHIP_REQUIRE(args->byteSize >= 32, "%s: args buffer of pass slot %u smaller than 32 bytes", ctx.shaderName, s);
+        const uint64_t cap = std::min<uint64_t>(rec->byteSize / sizeof(MeshletAmplificationData), mask->byteSize / 4);
+        TRHIP_REQUIRE(cap <= (1u << 27), "%s: more than 2^27 records cannot be encoded as (g<<5)|lane", ctx.shaderName);
+        a.records[s] = (uint32_t*)rec->ptr;
+        a.masks[s] = (uint32_t*)mask->ptr;
+        a.args[s] = (uint32_t*)args->ptr;
+        a.capacity[s] = (uint32_t)cap;
+        copyWords += 4ull * std::min<uint64_t>(cap, (uint64_t)a.world * a.slotGroups);
+        MeshletCullArgs& l = lists[s];
+        memset(&l, 0, sizeof l);
+        l.dispatchArgs = a.args[s];
+        l.argsWords = 4;
+        l.recordCapacity = a.capacity[s];
+        l.visMask = a.masks[s];
+        l.visibleList = (uint32_t*)list->ptr;
+        const uint64_t lcap = list->byteSize / 4;
+        l.listCapacity = lcap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)lcap;
+        l.drawArgs = a.args[s] + 4;
+        l.maxBatches = (l.recordCapacity + kBatch - 1) / kBatch;
+        l.batchSum = (uint32_t*)ctx.scratch((size_t)l.maxBatches * 4);
+        TRHIP_REQUIRE(l.batchSum, "%s: scratch allocation failed", ctx.shaderName);
+    }
+    uint32_t grid = ctx.computeUnits() * 4u;
+    const uint64_t need = (copyWords + 255u) / 256u;
+    if (grid > need) grid = (uint32_t)need;
+    if (grid == 0) grid = 1;
+    ctx.emit("concat", [a, grid](hipStream_t s) {
+        hipLaunchKernelGGL(shardConcatKernel, dim3(grid), dim3(256), 0, s, a);
+        return trhip::launchStatus("shardConcatKernel"); });
+    for (uint32_t s = 0; s < kMaxPassSlots; ++s)
+        if (a.records[s]) {
+            const char prefix[] = { 's', 'l', 'o', 't', (char)('0' + s), '_', 0 };
+            emitListBuild(ctx, lists[s], prefix);
+        }
+    return TRHIP_OK;
+}
+
+trhip::ShaderRegistrar rp("visibility_CS_PackShard", recordPackShard, 0);
+trhip::ShaderRegistrar ru("visibility_CS_UnpackShards", recordUnpackShards, 0);
 trhip::ShaderRegistrar r0("basepass_AS_Main LATE_CULL=0", recordASMain, 0);
 trhip::ShaderRegistrar r1("basepass_AS_Main LATE_CULL=1", recordASMain, 1);
 trhip::ShaderRegistrar r2("basepass_AS_Main_cull", recordASMain, 0);

@@ -40,6 +40,7 @@ struct InstanceCullArgs
     uint32_t* lateCount;
     uint32_t* lateIds;
     const uint32_t* indirectArgs;   // late: {ceil(count/64),1,1} (Q1)
+    const uint32_t* shardLate;      // late, multi-GPU only: {late entries of the lower ranks, of all ranks} (trhip.h)
     uint32_t directThreads;         // early: gx * 32
     uint32_t maxGroups;             // capacity of `records` (65535 in the reference, Q2)
     uint32_t argsWords;             // 3 or 4
@@ -84,6 +85,13 @@ __device__ __forceinline__ uint32_t threadCount(const InstanceCullArgs& a)
         // gpuculling.hlsl:94-103 with the dispatch size of :182-195 (Q1: ceil(count/64) groups of 32)
         uint32_t count = *a.lateCount;
         uint64_t launched = (uint64_t)a.indirectArgs[0] * kNumThreadsPerWave;
+        if (a.shardLate) {
+            // sharded instance list: the threads the single-GPU dispatch launches cover the first
+            // ceil(total/64)*32 entries of the rank-major concatenation of the late lists; this
+            // rank's entries start at shardLate[0] in it
+            const uint64_t all = (((uint64_t)a.shardLate[1] + 63u) / 64u) * kNumThreadsPerWave;
+            launched = all > a.shardLate[0] ? all - a.shardLate[0] : 0u;
+        }
         uint32_t n = launched < count ? (uint32_t)launched : count;
         return n < a.k.m_NbInstances ? n : a.k.m_NbInstances;
     }
@@ -325,6 +333,18 @@ __global__ void buildLateCullIndirectArgsKernel(const uint32_t* count, uint32_t*
     args[2] = 1;
 }
 
+__global__ void shardLateInfoKernel(const uint32_t* counts, uint32_t world, uint32_t rank, uint32_t* info)
+{
+    uint32_t below = 0, all = 0;
+    for (uint32_t p = 0; p < world; ++p) {
+        const uint32_t c = counts[p];
+        if (p < rank) below += c;
+        all += c;
+    }
+    info[0] = below;
+    info[1] = all;
+}
+
 int fillHzb(const trhip::DispatchCtx& ctx, trhip_texture_t* tex, const Vector2U& dims, bool occlusion, cm::Hzb* out)
 {
     memset(out, 0, sizeof *out);
@@ -353,6 +373,8 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
     trhip_buffer_t* args = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 1);
     trhip_buffer_t* lateCount = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 2);
     trhip_buffer_t* lateIds = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 3);
+    trhip_buffer_t* shardLate = LATE ? ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 4) : nullptr;   // optional, multi-GPU only
+    TRHIP_REQUIRE(!shardLate || shardLate->byteSize >= 8, "%s: shard late info (t4) smaller than 8 bytes", ctx.shaderName);
     TRHIP_REQUIRE(instances && ids && meshData && records && args && lateCount && lateIds,
                   "%s: needs SRVs t0..t2 and UAVs u0..u3 (BasePassRenderers.cpp:351-362)", ctx.shaderName);
     const bool occlusion = (k->m_CullingFlags & kCullingFlagOcclusionCullingEnable) != 0;
@@ -385,6 +407,7 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
     a.lateCount = (uint32_t*)lateCount->ptr;
     a.lateIds = (uint32_t*)lateIds->ptr;
     a.indirectArgs = LATE ? (const uint32_t*)((const char*)ctx.argsBuffer->ptr + ctx.argsOffset) : nullptr;
+    a.shardLate = shardLate ? (const uint32_t*)shardLate->ptr : nullptr;
     const uint64_t direct = (uint64_t)ctx.gx * kNumThreadsPerWave;
     a.directThreads = direct > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)direct;
     const uint64_t cap = records->byteSize / sizeof(MeshletAmplificationData);
@@ -454,3 +477,11 @@ trhip::ShaderRegistrar r1("gpuculling_CS_GPUCulling LATE_CULL=1", recordGPUCulli
 trhip::ShaderRegistrar r2("gpuculling_CS_BuildLateCullIndirectArgs", recordBuildLateArgs, 0);
 
 } // namespace
+
+extern "C" int trhip_launch_shard_late_info(void* hip_stream, const uint32_t* gathered_counts, uint32_t world, uint32_t rank, uint32_t* info)
+{
+    if (!gathered_counts || !info || world == 0 || rank >= world)
+        return trhip::fail(TRHIP_ERR_INVALID, "launch_shard_late_info: bad arguments (world %u, rank %u)", world, rank);
+    hipLaunchKernelGGL(shardLateInfoKernel, dim3(1), dim3(1), 0, (hipStream_t)hip_stream, gathered_counts, world, rank, info);
+    return trhip::launchStatus("shardLateInfoKernel");
+}

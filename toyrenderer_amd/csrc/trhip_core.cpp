@@ -544,6 +544,14 @@ int trhip_cmd_copy_buffer(trhip_cmdlist cl, trhip_buffer dst, uint64_t dstOff, t
     return TRHIP_OK;
 }
 
+int trhip_cmd_host_callback(trhip_cmdlist cl, trhip_host_fn fn, void* user)
+{
+    TRHIP_RECORDING(cl);
+    if (!fn) return fail(TRHIP_ERR_INVALID, "host_callback: null function");
+    cl->ops.push_back({ "", [fn, user](hipStream_t s) { fn(user, (void*)s); return (int)TRHIP_OK; } });
+    return TRHIP_OK;
+}
+
 int trhip_cmd_copy_texture(trhip_cmdlist cl, trhip_texture dst, trhip_texture src)
 {
     TRHIP_RECORDING(cl);

@@ -57,9 +57,14 @@ class FrameDriver:
     """BasePassRenderer (Setup + RenderBasePass) over rhi.  One command list per frame."""
 
     def __init__(self, dev: rhi.Device, scene: GpuScene, view, *, record_capacity: int, list_capacity: int | None = None,
-                 culling_flags: int = 7, force_mesh_lod: int = -1, freeze_culling_camera: bool = False, alloc=None):
+                 culling_flags: int = 7, force_mesh_lod: int = -1, freeze_culling_camera: bool = False, alloc=None,
+                 shard_late=None):
         """alloc(nbytes, name, stride, indirect) -> rhi.Buffer or None: lets the caller own the memory of the
-        output buffers (e.g. torch tensors handed to RCCL, gather.py); None -> device allocation."""
+        output buffers (e.g. torch tensors handed to RCCL, gather.py); None -> device allocation.
+        shard_late(hip_stream, late_count_ptr, shard_info_ptr, bucket): multi-GPU hook, called while the
+        frame is submitted, before each late instance cull (same contract as include/trhost.h)."""
+        self.shard_late = shard_late
+        self.shardInfo = [dev.create_buffer(8, f"ShardLateInfo{b}") for b in (0, 1)] if shard_late is not None else None
         self.dev, self.scene, self.view = dev, scene, view
         self.flags = culling_flags & 7
         self.force_mesh_lod = force_mesh_lod
@@ -155,6 +160,11 @@ class FrameDriver:
             if occ:                                                                       # :377-389
                 cl.dispatch("gpuculling_CS_BuildLateCullIndirectArgs", [SRV(0, late_count), UAV(0, late_args)], (1, 1, 1))
         elif occ:
+            if self.shard_late is not None:                                               # multi-GPU only (trhost.h)
+                bucket = int(alpha_mask)
+                info = self.shardInfo[bucket]
+                cl.host_callback(lambda stream, c=late_count.ptr, i=info.ptr, b=bucket: self.shard_late(stream, c, i, b))
+                bindings.append(SRV(4, info))
             cl.dispatch_indirect(name, bindings, late_args)                               # :392-402
         else:
             return False
@@ -243,6 +253,6 @@ class FrameDriver:
         for lst in (self.records, self.dispatchArgs, self.visMask, self.visibleList, self.drawArgs):
             for b in lst:
                 b.release()
-        for b in (self.lateArgs, self.lateCount, self.lateIds, self.spdAtomic, self.dummy):
+        for b in (self.lateArgs, self.lateCount, self.lateIds, self.spdAtomic, self.dummy, *(self.shardInfo or ())):
             b.release()
         self.hzb.release(); self.depth.release()

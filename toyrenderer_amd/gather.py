@@ -1,19 +1,45 @@
 """Multi-GPU exchange of the visibility results: one process per GPU, instances sharded by
-contiguous ranges, per-rank visible lists + amplification records all-gathered over RCCL/xGMI so
-that every rank ends the frame with the whole scene's lists in the single-GPU canonical order
-(rank-major concatenation).  Not in the reference (single GPU, GraphicRHI.cpp:165).
+contiguous ranges; every rank ends the frame with the WHOLE scene's amplification records and ordered
+visible lists, bit-identical to a single-GPU frame (rank-major concatenation == single-GPU canonical
+order).  Not in the reference (single GPU, GraphicRHI.cpp:165).
 
-Per frame and pass slot (early / late):
-  1. all-gather of {groups G_r, visible V_r} per rank                        (tiny, fixed size)
-  2. host reads the counts (one sync) and derives the offsets
-  3. own list entries (g << 5 | lane) are rebased by sum_{p<r} G_p           (HIP kernel, in place)
-  4. variable-length all-gather of lists (4 B x V_r) and records (12 B x G_r)
-The 2-phase structure needs no collective between the phases (late lists stay rank-local).
-torch.distributed is plumbing here (process group + RCCL calls on torch's current stream).
+What crosses xGMI is the compact form of a rank's pass slots -- per group of 32 meshlets the 12-byte
+record and the 4-byte lane mask (1 bit per tested meshlet instead of 4 bytes per visible meshlet: 28 MB
+instead of 143 MB per frame on the 100 M-meshlet config) -- in one fixed-capacity SHARD SLOT per rank:
+
+    words [0, 16)             header: {G_s, V_s} of pass slot s at words 2s, 2s+1; word 8 = overflow flag
+    words [16, 16+3S)         records of pass slot 0, then 1, ... back to back (S = slot_groups)
+    words [16+3S, 16+4S)      lane masks in the same order
+
+Per frame:  pack (HIP kernel, compute stream)  ->  ONE equal-size all_gather_into_tensor (RCCL)  ->
+unpack (HIP kernels: rank-major concatenation with device-side offsets from the headers, then the same
+count/scan/expand list build the single-GPU path uses).  There is no host read-back, so nothing stalls
+the submission of the next frame; the collective and the unpack run on a second stream and overlap the
+next frame's culling (send/receive buffers are double-buffered and guarded by events).
+
+One more, tiny, collective sits INSIDE the frame: the reference sizes the late instance cull from the
+late-list length (gpuculling.hlsl:182-195: ceil(count/64) groups of 32 threads, i.e. only the first
+ceil(count/64)*32 entries are processed).  For the sharded run to equal the single-GPU run that rule must
+see the whole scene's late list, so before each late instance cull the ranks all-gather their late
+counts (4 bytes each, device to device, no host read-back) and a one-thread kernel derives {entries of
+the lower ranks, entries of all ranks} for the late dispatch (`late_exchange`, hooked into the frame
+through trhost_set_shard_late_exchange / FrameDriver(shard_late=...)).
+Group-capacity overflow (the reference's 65 535-group cap, Q2) is NOT made global: a sharded run equals
+the single-GPU run only if no rank drops groups; a rank that does raises STATUS_GROUPS_DROPPED.
+torch.distributed is plumbing here (process group + the RCCL calls).
 """
 from __future__ import annotations
 
+import contextlib
+
 import numpy as np
+
+HEADER_WORDS = 16
+MAX_PASS_SLOTS = 4
+STATUS_SLOT_OVERFLOW = 1      # a rank produced more groups than its shard slot holds
+STATUS_CAPACITY = 2           # the whole-scene buffers are smaller than the gathered total
+STATUS_BAD_HEADER = 4
+STATUS_GROUPS_DROPPED = 8      # a rank hit its group capacity (Q2): the sharded result differs from single-GPU
 
 
 def exclusive_offsets(counts):
@@ -30,115 +56,218 @@ def shard_range(n: int, rank: int, world: int):
     return (rank * n) // world, ((rank + 1) * n) // world
 
 
-def all_gather_varlen(dist, out, local, counts, rank, uneven_ok: bool):
-    """Gather `local[:counts[rank]]` of every rank into `out` at the exclusive offsets of `counts`
-    (1-D tensors of one dtype).  RCCL: one coalesced uneven all_gather; gloo (CPU tests): broadcasts."""
-    offs, total = exclusive_offsets(counts)
-    assert out.numel() >= total, (out.numel(), total)
-    views = [out[offs[p]:offs[p] + int(counts[p])] for p in range(len(counts))]
-    if uneven_ok:
-        dist.all_gather(views, local[:int(counts[rank])])
-    else:
-        views[rank].copy_(local[:int(counts[rank])])
-        for p in range(len(counts)):
-            if int(counts[p]):
-                dist.broadcast(views[p], src=p)
-    return offs, total
+def slot_words(slot_groups: int) -> int:
+    return HEADER_WORDS + 4 * int(slot_groups)
 
 
-def exchange_counts(dist, torch, local_counts, world):
-    """local_counts: 1-D int32 tensor -> numpy [world, n] on the host (the frame's one host sync)."""
-    parts = [torch.empty_like(local_counts) for _ in range(world)]
-    dist.all_gather(parts, local_counts)
-    return torch.stack(parts).cpu().numpy().astype(np.int64)
+def shard_group_capacity(num_meshlets_per_lod: np.ndarray, mesh_of_entry: np.ndarray) -> int:
+    """Upper bound of the groups one shard can emit in a frame over ALL its pass slots: every list entry
+    submitted once (early and late sets are disjoint) at its largest LOD.
+    num_meshlets_per_lod: [meshes, lods]; mesh_of_entry: mesh index of every id-list entry of the shard."""
+    per_mesh = ((np.asarray(num_meshlets_per_lod, np.int64) + 31) // 32).max(axis=1)
+    return int(per_mesh[np.asarray(mesh_of_entry, np.int64)].sum())
 
 
-def gather_slot(dist, rank, world, out_list, out_records, local_list, local_records, G, V, rebase, uneven_ok):
-    """One pass slot.  G, V: per-rank group / visible counts (host, length world).  `rebase(add)` adds
-    `add` to the first V[rank] entries of local_list in place (HIP kernel on the GPU path).
-    Returns (total groups, total visible)."""
-    gbase = int(sum(G[:rank]))
-    if gbase and V[rank]:
-        rebase(gbase << 5)
-    _, v_tot = all_gather_varlen(dist, out_list, local_list, V, rank, uneven_ok)
-    _, g3_tot = all_gather_varlen(dist, out_records, local_records, [3 * int(g) for g in G], rank, uneven_ok)
-    return g3_tot // 3, v_tot
+def agree_slot_groups(dist, torch, local_capacity: int, device="cpu") -> int:
+    """All ranks must use one slot size: the maximum of the per-rank capacities (setup time, once)."""
+    t = torch.tensor([int(local_capacity)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
 
 
-class _DevArray:
+class ShardExchange:
+    """Host logic of the exchange (buffers, double buffering, the one collective per frame).  The data
+    movers are hooks: `_pack(b)` fills send[b] from the local pass slots, `_unpack(b)` turns recv[b] into
+    the whole-scene outputs.  HipShardExchange implements them with the gfx950 kernels."""
+
+    def __init__(self, dist, torch, world: int, rank: int, slot_groups: int, pass_slots=(0, 1),
+                 group_capacity: int | None = None, list_capacity: int | None = None, device="cpu"):
+        assert 1 <= len(pass_slots) <= MAX_PASS_SLOTS and all(0 <= s < MAX_PASS_SLOTS for s in pass_slots)
+        self.dist, self.torch, self.world, self.rank = dist, torch, int(world), int(rank)
+        self.slot_groups = int(slot_groups)
+        self.slot_words = slot_words(slot_groups)
+        assert self.world * self.slot_words < 2 ** 32, "gathered buffer exceeds 2^32 words"
+        self.pass_slots = tuple(pass_slots)
+        self.group_capacity = int(group_capacity if group_capacity is not None else self.world * self.slot_groups)
+        assert self.group_capacity <= 1 << 27, "more than 2^27 groups cannot be encoded as (g << 5) | lane"
+        self.list_capacity = int(list_capacity if list_capacity is not None else 32 * self.group_capacity)
+        self.device = device
+        i32 = torch.int32
+        self.send = [torch.zeros(self.slot_words, dtype=i32, device=device) for _ in range(2)]
+        self.recv = [torch.zeros(self.world * self.slot_words, dtype=i32, device=device) for _ in range(2)]
+        self.out = {s: dict(records=torch.zeros(3 * max(self.group_capacity, 1), dtype=i32, device=device),
+                            masks=torch.zeros(max(self.group_capacity, 1), dtype=i32, device=device),
+                            list=torch.zeros(max(self.list_capacity, 1), dtype=i32, device=device),
+                            args=torch.zeros(8, dtype=i32, device=device)) for s in self.pass_slots}
+        self.frame = 0
+
+    # ---- hooks -------------------------------------------------------------------------------------
+    def _pack(self, b: int):
+        raise NotImplementedError
+
+    def _unpack(self, b: int):
+        raise NotImplementedError
+
+    def _begin(self, b: int):
+        """Before send[b] is overwritten: the exchange that last used buffers b must be done."""
+
+    def _comm(self, b: int):
+        """Context in which the collective and the unpack of buffers b are issued."""
+        return contextlib.nullcontext()
+
+    def wait(self):
+        """Block until every exchange issued so far has completed."""
+
+    # ---- per frame ---------------------------------------------------------------------------------
+    def run(self):
+        b = self.frame & 1
+        self._begin(b)
+        self._pack(b)
+        with self._comm(b):
+            self.dist.all_gather_into_tensor(self.recv[b], self.send[b])
+            self._unpack(b)
+        self.frame += 1
+
+    def results(self, pass_slot: int):
+        """(records[G,3], visible list[V]) of the whole scene for one pass slot, as u32 (host copy).
+        Raises if a slot or the whole-scene buffers overflowed."""
+        self.wait()
+        o = self.out[pass_slot]
+        args = o["args"].cpu().numpy().view(np.uint32)
+        G, V, status = int(args[0]), int(args[4]), int(args[7])
+        if status:
+            raise RuntimeError(f"shard exchange failed (status {status}): "
+                               + ("a rank's groups exceed slot_groups; " if status & STATUS_SLOT_OVERFLOW else "")
+                               + ("whole-scene capacity exceeded; " if status & STATUS_CAPACITY else "")
+                               + ("corrupt slot header; " if status & STATUS_BAD_HEADER else "")
+                               + ("a rank dropped groups at its capacity (Q2)" if status & STATUS_GROUPS_DROPPED else ""))
+        if V > self.list_capacity:
+            raise RuntimeError(f"whole-scene visible list holds {self.list_capacity} entries, frame produced {V}")
+        return (o["records"][:3 * G].cpu().numpy().view(np.uint32).reshape(-1, 3),
+                o["list"][:V].cpu().numpy().view(np.uint32))
+
+
+class _DevWords:
     """Device memory owned by the back end, viewed by torch through __cuda_array_interface__."""
 
     def __init__(self, ptr: int, n: int):
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
 
 
-class VisibleListGather:
-    """GPU path: gathers the outputs of the C++ host mirror's pass slots 0 (early) and 1 (late)."""
+def shard_late_info(counts, rank: int):
+    """{late entries of the lower ranks, of all ranks} -- what trhip_launch_shard_late_info computes."""
+    counts = [int(c) for c in counts]
+    return sum(counts[:rank]), sum(counts)
 
-    SLOTS = (0, 1)
 
-    def __init__(self, renderer, dist, world: int, rank: int, global_record_cap: int):
+class HipShardExchange(ShardExchange):
+    """GPU path over the C++ host mirror: packs the renderer's pass slots on its stream, gathers and
+    unpacks on a second stream (overlap=True) so the next frame's culling runs meanwhile."""
+
+    def __init__(self, renderer, dist, world: int, rank: int, slot_groups: int, pass_slots=(0, 1),
+                 group_capacity: int | None = None, list_capacity: int | None = None, overlap: bool = True):
         import torch
 
         from . import rhi
-        self.torch, self.rhi, self.r, self.dist, self.world, self.rank = torch, rhi, renderer, dist, world, rank
-        self.dev = rhi.Device(handle=renderer.device())
-        self.all_lists = [torch.empty(global_record_cap * 32, dtype=torch.int32, device="cuda") for _ in self.SLOTS]
-        self.all_records = [torch.empty(global_record_cap * 3, dtype=torch.int32, device="cuda") for _ in self.SLOTS]
-        self.counts_local = torch.zeros(2 * len(self.SLOTS), dtype=torch.int32, device="cuda")
-        self.counts_buf = self.dev.wrap_buffer(self.counts_local.data_ptr(), 16, "GatherCounts")
-        self.cl = self.dev.create_command_list()
-        self.last_counts = None
-        self.totals = None
-        self._views = {}
+        super().__init__(dist, torch, world, rank, slot_groups, pass_slots, group_capacity, list_capacity, device="cuda")
+        self.rhi, self.r = rhi, renderer
+        L = rhi.load()
+        self.dev = rhi.Device(handle=renderer.device())                       # the renderer's device (compute stream)
+        self.compute = torch.cuda.ExternalStream(int(L.trhip_device_stream(self.dev.h) or 0))
+        self.overlap = bool(overlap)
+        if self.overlap:
+            self.comm = torch.cuda.Stream()
+            self.comm_dev = rhi.Device(torch.cuda.current_device(), stream=self.comm.cuda_stream)
+        else:
+            self.comm, self.comm_dev = self.compute, self.dev
+        self.packed = [torch.cuda.Event() for _ in range(2)]
+        self.released = [torch.cuda.Event() for _ in range(2)]
+        self.send_buf = [self.dev.wrap_buffer(t.data_ptr(), t.numel() * 4, f"ShardSlotSend{i}") for i, t in enumerate(self.send)]
+        self.pack_cl = [self.dev.create_command_list() for _ in range(2)]
+        # the unpack only touches buffers owned here: recorded once per buffer index
+        self.unpack_cl = []
+        push = np.array([self.world, self.slot_groups], np.uint32)
+        self._wrapped = []
+        for b in range(2):
+            cl = self.comm_dev.create_command_list()
+            binds = [rhi.PUSH(0), rhi.SRV(0, self._wrap(self.recv[b], f"ShardSlotsRecv{b}"))]
+            for s in self.pass_slots:
+                o = self.out[s]
+                binds += [rhi.UAV(4 * s, self._wrap(o["records"], f"AllRecords{s}")), rhi.UAV(4 * s + 1, self._wrap(o["masks"], f"AllMasks{s}")),
+                          rhi.UAV(4 * s + 2, self._wrap(o["list"], f"AllVisibleList{s}")), rhi.UAV(4 * s + 3, self._wrap(o["args"], f"AllArgs{s}"))]
+            cl.open()
+            cl.dispatch("visibility_CS_UnpackShards", binds, (1, 1, 1), push=push)
+            cl.close()
+            self.unpack_cl.append(cl)
 
-    def _tensor(self, handle, nwords):
-        L = self.rhi.load()
-        ptr = L.trhip_buffer_device_ptr(handle)
-        key = (ptr, nwords)
-        t = self._views.get(key)
-        if t is None:
-            t = self.torch.as_tensor(_DevArray(ptr, nwords), device="cuda")
-            self._views[key] = t
-        return t
+        # in-frame exchange of the late-list lengths (module docstring)
+        self.late_counts = [torch.zeros(self.world, dtype=torch.int32, device="cuda") for _ in range(2)]
+        self._ptr_views = {}
+        self._hook_error = None
+        renderer.set_shard_late_exchange(self.late_exchange)
 
-    def run(self):
-        torch, L, rhi = self.torch, self.rhi.load(), self.rhi
-        pbs = [self.r.pass_buffers(s) for s in self.SLOTS]
-        # 1. {G0, V0, G1, V1} with one tiny kernel into a torch-owned 16-byte tensor
-        cl = self.cl
+    def late_exchange(self, hip_stream: int, late_count_ptr: int, shard_info_ptr: int, bucket: int):
+        """Runs inside renderer.frame(), on the compute stream, before a late instance cull."""
+        try:
+            t = self._ptr_views.get(late_count_ptr)
+            if t is None:
+                t = self._ptr_views[late_count_ptr] = self.torch.as_tensor(_DevWords(late_count_ptr, 1), device="cuda")
+            with self.torch.cuda.stream(self.compute):
+                self.dist.all_gather_into_tensor(self.late_counts[bucket], t)
+            rc = self.rhi.load().trhip_launch_shard_late_info(hip_stream, self.late_counts[bucket].data_ptr(), self.world, self.rank, shard_info_ptr)
+            if rc != 0:
+                raise RuntimeError(self.rhi.load().trhip_last_error().decode(errors="replace"))
+        except Exception as e:      # a ctypes callback cannot propagate: re-raised by run()
+            self._hook_error = e
+
+    def _wrap(self, t, name):
+        buf = self.comm_dev.wrap_buffer(t.data_ptr(), t.numel() * 4, name)
+        self._wrapped.append(buf)
+        return buf
+
+    def _begin(self, b):
+        if self._hook_error is not None:
+            e, self._hook_error = self._hook_error, None
+            raise e
+        self.compute.wait_event(self.released[b])
+
+    def _pack(self, b):
+        rhi = self.rhi
+        binds = [rhi.PUSH(0), rhi.UAV(0, self.send_buf[b])]
+        for s in self.pass_slots:
+            pb = self.r.pass_buffers(s)
+            if not pb.ran:
+                continue
+            for k, h in enumerate((pb.records, pb.vis_mask, pb.dispatch_args, pb.draw_args)):
+                x = rhi.bind(rhi.BIND_STRUCTURED_SRV, 4 * s + k)
+                x.resource = h
+                binds.append(x)
+        cl = self.pack_cl[b]
         cl.open()
-        b = []
-        for i, pb in enumerate(pbs):
-            if pb.ran:
-                x, y = rhi.bind(rhi.BIND_STRUCTURED_SRV, 2 * i), rhi.bind(rhi.BIND_STRUCTURED_SRV, 2 * i + 1)
-                x.resource, y.resource = pb.dispatch_args, pb.draw_args
-                b += [x, y]
-        b.append(rhi.UAV(0, self.counts_buf))
-        cl.dispatch("visibility_CS_PackCounts", b, (1, 1, 1))
+        cl.dispatch("visibility_CS_PackShard", binds, (1, 1, 1), push=np.array([self.slot_groups], np.uint32))
         cl.close()
         self.dev.execute(cl)
-        c = exchange_counts(self.dist, torch, self.counts_local, self.world)          # 2. the frame's one host sync
-        self.last_counts = c
-        self.totals = []
-        for i, pb in enumerate(pbs):
-            G, V = c[:, 2 * i], c[:, 2 * i + 1]
-            if not pb.ran:
-                self.totals.append((0, 0))
-                continue
-            lst = self._tensor(pb.visible_list, L.trhip_buffer_size(pb.visible_list) // 4)
-            rec = self._tensor(pb.records, L.trhip_buffer_size(pb.records) // 4)
+        self.packed[b].record(self.compute)
 
-            def rebase(add, pb=pb):                                                    # 3. rebase own entries (HIP kernel)
-                cl.open()
-                bb = [rhi.PUSH(0), rhi.bind(rhi.BIND_STRUCTURED_UAV, 0), rhi.bind(rhi.BIND_STRUCTURED_SRV, 0)]
-                bb[1].resource, bb[2].resource = pb.visible_list, pb.draw_args
-                cl.dispatch("visibility_CS_RebaseVisibleList", bb, (1, 1, 1), push=np.array([add >> 5], np.uint32))
-                cl.close()
-                self.dev.execute(cl)
-            self.totals.append(gather_slot(self.dist, self.rank, self.world, self.all_lists[i], self.all_records[i], lst, rec, G, V, rebase, True))   # 4.
+    @contextlib.contextmanager
+    def _comm(self, b):
+        self.comm.wait_event(self.packed[b])
+        with self.torch.cuda.stream(self.comm):
+            yield
+            self.released[b].record(self.comm)
 
-    def results(self, slot_index: int):
-        G, V = self.totals[slot_index]
-        return (self.all_records[slot_index][:G * 3].cpu().numpy().view(np.uint32).reshape(-1, 3),
-                self.all_lists[slot_index][:V].cpu().numpy().view(np.uint32))
+    def _unpack(self, b):
+        self.comm_dev.execute(self.unpack_cl[b])
+
+    def wait(self):
+        self.comm.synchronize()
+
+    def close(self):
+        self.wait()
+        self.r.set_shard_late_exchange(None)
+        for cl in self.pack_cl + self.unpack_cl:
+            cl.release()
+        for buf in self.send_buf + self._wrapped:
+            buf.release()
+        if self.overlap:
+            self.comm_dev.destroy()

@@ -30,12 +30,15 @@ ABI_SYMBOLS = [
     "trhip_texture_release", "trhip_texture_device_ptr", "trhip_texture_mip_info", "trhip_texture_size",
     "trhip_buffer_upload", "trhip_buffer_download", "trhip_texture_upload", "trhip_texture_download",
     "trhip_cmd_create", "trhip_cmd_release", "trhip_cmd_open", "trhip_cmd_close", "trhip_cmd_write_buffer",
-    "trhip_cmd_clear_buffer_u32", "trhip_cmd_clear_texture_f32", "trhip_cmd_copy_buffer", "trhip_cmd_copy_texture", "trhip_cmd_dispatch", "trhip_cmd_dispatch_indirect",
+    "trhip_cmd_clear_buffer_u32", "trhip_cmd_clear_texture_f32", "trhip_cmd_copy_buffer", "trhip_cmd_copy_texture", "trhip_cmd_host_callback", "trhip_cmd_dispatch", "trhip_cmd_dispatch_indirect",
     "trhip_cmd_begin_timer", "trhip_cmd_end_timer", "trhip_cmd_begin_marker", "trhip_cmd_end_marker",
     "trhip_queue_execute",
     "trhip_timer_create", "trhip_timer_release", "trhip_timer_get_ms",
     "trhip_profile_enable", "trhip_profile_reset", "trhip_profile_count", "trhip_profile_entry",
+    "trhip_launch_shard_late_info",
 ]
+
+HOST_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)       # trhip_host_fn(user, hip_stream)
 
 
 class BufferDesc(C.Structure):
@@ -120,6 +123,8 @@ def load() -> C.CDLL:
     L.trhip_cmd_clear_texture_f32.argtypes = [vp, vp, C.c_float]
     L.trhip_cmd_copy_buffer.argtypes = [vp, vp, u64, vp, u64, u64]
     L.trhip_cmd_copy_texture.argtypes = [vp, vp, vp]
+    L.trhip_cmd_host_callback.argtypes = [vp, HOST_FN, vp]
+    L.trhip_launch_shard_late_info.argtypes = [vp, vp, u32, u32, vp]
     L.trhip_cmd_dispatch.argtypes = [vp, C.c_char_p, C.POINTER(Binding), u32, vp, u32, u32, u32, u32]
     L.trhip_cmd_dispatch_indirect.argtypes = [vp, C.c_char_p, C.POINTER(Binding), u32, vp, u32, vp, u32]
     L.trhip_cmd_begin_timer.argtypes = [vp, vp]
@@ -244,9 +249,11 @@ class CommandList:
     def __init__(self, dev: "Device", handle):
         self.dev, self.h = dev, handle
         self._keep = []
+        self._keep_cb = []
 
     def open(self):
         self._keep.clear()
+        self._keep_cb = []
         _check(load().trhip_cmd_open(self.h))
         return self
 
@@ -288,6 +295,12 @@ class CommandList:
         arr = (Binding * len(bindings))(*bindings)
         p, pb = (None, 0) if push is None else (np.ascontiguousarray(push).ctypes.data, np.ascontiguousarray(push).nbytes)
         _check(load().trhip_cmd_dispatch_indirect(self.h, shader.encode(), arr, len(bindings), p, pb, args.h, offset))
+
+    def host_callback(self, fn):
+        """fn(hip_stream: int) is called while the list is executed, in order (include/trhip.h)."""
+        cb = HOST_FN(lambda _user, stream: fn(int(stream or 0)))
+        self._keep_cb.append(cb)
+        _check(load().trhip_cmd_host_callback(self.h, cb, None))
 
     def begin_timer(self, t: Timer): _check(load().trhip_cmd_begin_timer(self.h, t.h))
     def end_timer(self, t: Timer): _check(load().trhip_cmd_end_timer(self.h, t.h))
