@@ -179,11 +179,20 @@ def main():
                                   group_capacity=spec.num_instances * groups_per_instance,
                                   overlap=not os.environ.get("TR_NO_OVERLAP"))
 
+    cpu_t = [0.0, 0.0, 0.0, 0.0]                          # host time spent submitting: frame, exchange (diagnostics, stderr only)
+
     def step():
+        t_a = time.perf_counter()
         r.set_camera(view)
         r.frame()
+        t_b = time.perf_counter()
+        rec_ms, sub_ms = r.renderer_times("<frame>")
+        cpu_t[2] += rec_ms
+        cpu_t[3] += sub_ms
         if gather:
             gather.run()
+        cpu_t[0] += t_b - t_a
+        cpu_t[1] += time.perf_counter() - t_b
 
     def sync():
         torch.cuda.synchronize()          # all streams of the device, including the exchange's
@@ -195,10 +204,14 @@ def main():
         step()
     sync()
     t0 = time.perf_counter()
+    cpu_t[:] = [0.0] * 4
     for _ in range(args.steps):
         step()
+    t_submit = time.perf_counter() - t0
     sync()
     dt = time.perf_counter() - t0
+    log(f"[rank {rank}] host submission per step: frame {cpu_t[0] / args.steps * 1e3:.3f} ms (record {cpu_t[2] / args.steps:.3f}, submit {cpu_t[3] / args.steps:.3f}), exchange {cpu_t[1] / args.steps * 1e3:.3f} ms; "
+        f"all steps submitted after {t_submit * 1e3:.2f} ms of {dt * 1e3:.2f} ms")
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -81,6 +81,7 @@ typedef void (*trhost_shard_late_fn)(void* user, void* hip_stream, void* late_co
 int  trhost_set_shard_late_exchange(trhost_shard_late_fn fn, void* user);
 
 int  trhost_render_graph_stats(uint32_t* num_heaps, uint64_t* bytes_reserved, uint64_t* bytes_used, uint32_t* num_passes);
+/* renderer_name "<frame>": host milliseconds the last trhost_frame spent recording (cpu_ms) and submitting (gpu_ms). */
 int  trhost_renderer_times(const char* renderer_name, float* cpu_ms, float* gpu_ms);
 
 /* Test hook (no GPU): drives RenderGraph::Heap's free-list allocator (RenderGraph.cpp:443-580).

@@ -2,6 +2,8 @@
 // source/Graphic.cpp and source/GraphicRHI.cpp.
 #include "Graphic.h"
 
+#include <chrono>
+
 #include "CommonResources.h"
 #include "GraphicConstants.h"
 #include "RenderGraph.h"
@@ -82,9 +84,14 @@ void Graphic::Shutdown()
 void Graphic::Update()
 {
     ++m_FrameCounter;                                                         // Graphic.cpp:706
+    const auto t0 = std::chrono::steady_clock::now();
     m_Scene->Update();                                                        // records every pass
+    const auto t1 = std::chrono::steady_clock::now();
     ExecuteAllCommandLists();                                                 // the CPU->GPU boundary
     m_NVRHIDevice->runGarbageCollection();                                    // Graphic.cpp:761-765
+    const auto t2 = std::chrono::steady_clock::now();
+    m_LastRecordMs = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    m_LastSubmitMs = std::chrono::duration<float, std::milli>(t2 - t1).count();
 }
 
 bool Graphic::HasShader(std::string_view shaderBinName) const

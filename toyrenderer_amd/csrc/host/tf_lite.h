@@ -1,6 +1,6 @@
 // tf_lite.h -- the slice of Taskflow the frame schedule uses (extern/taskflow is an empty
 // submodule in the reference snapshot): Taskflow::emplace / placeholder, Task::succeed / precede,
-// Executor::corun.  Tasks run on a small pool of std::threads in dependency order, so Render()
+// Executor::corun.  Tasks run on a small persistent pool of std::threads in dependency order, so Render()
 // really is called from arbitrary worker threads like in the reference (RenderGraph.cpp:254-288).
 #pragma once
 
@@ -68,50 +68,88 @@ inline Task& Task::precede(const Task& other)
 class Executor
 {
 public:
-    explicit Executor(unsigned workers = 4) : m_Workers(workers ? workers : 1) {}
+    // The workers are created once and parked on a condition variable between frames (spawning
+    // threads per corun costs ~0.1 ms per frame, as much as recording the whole visibility path).
+    explicit Executor(unsigned workers = 4)
+    {
+        for (unsigned i = 1; i < (workers ? workers : 1u); ++i) m_Threads.emplace_back([this] { workerLoop(); });
+    }
+    ~Executor()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_Mutex);
+            m_Stop = true;
+        }
+        m_Cv.notify_all();
+        for (std::thread& t : m_Threads) t.join();
+    }
+    Executor(const Executor&) = delete;
+    Executor& operator=(const Executor&) = delete;
 
     // Runs every task of the flow (the caller participates), returns when all are done.
     void corun(Taskflow& flow)
     {
         const size_t n = flow.m_Nodes.size();
         if (n == 0) return;
-        std::vector<std::atomic<size_t>> pending(n);
-        std::vector<size_t> ready;
+        Job job;
+        job.flow = &flow;
+        job.pending.resize(n);
         for (size_t i = 0; i < n; ++i) {
-            pending[i].store(flow.m_Nodes[i].numDeps);
-            if (flow.m_Nodes[i].numDeps == 0) ready.push_back(i);
+            job.pending[i] = flow.m_Nodes[i].numDeps;
+            if (flow.m_Nodes[i].numDeps == 0) job.ready.push_back(i);
         }
-        std::mutex mtx;
-        std::condition_variable cv;
-        size_t done = 0;
-        auto worker = [&] {
-            for (;;) {
-                size_t idx;
-                {
-                    std::unique_lock<std::mutex> lk(mtx);
-                    cv.wait(lk, [&] { return !ready.empty() || done == n; });
-                    if (ready.empty()) return;
-                    idx = ready.back();
-                    ready.pop_back();
-                }
-                flow.m_Nodes[idx].fn();
-                {
-                    std::lock_guard<std::mutex> lk(mtx);
-                    ++done;
-                    for (size_t s : flow.m_Nodes[idx].successors)
-                        if (pending[s].fetch_sub(1) == 1) ready.push_back(s);
-                }
-                cv.notify_all();
-            }
-        };
-        std::vector<std::thread> threads;
-        for (unsigned i = 1; i < m_Workers; ++i) threads.emplace_back(worker);
-        worker();
-        for (std::thread& t : threads) t.join();
+        std::unique_lock<std::mutex> lk(m_Mutex);
+        m_Job = &job;
+        if (job.ready.size() > 1) m_Cv.notify_all();
+        for (;;) {
+            runReady(lk);
+            if (job.done == n) break;
+            m_Cv.wait(lk, [&] { return job.done == n || !job.ready.empty(); });
+        }
+        m_Job = nullptr;                       // no task is running any more: nobody else refers to `job`
     }
 
 private:
-    unsigned m_Workers;
+    struct Job
+    {
+        Taskflow* flow = nullptr;
+        std::vector<size_t> pending, ready;
+        size_t done = 0;
+    };
+
+    // Called with the lock held; returns with it held.
+    void runReady(std::unique_lock<std::mutex>& lk)
+    {
+        while (m_Job && !m_Job->ready.empty()) {
+            Job* job = m_Job;
+            const size_t idx = job->ready.back();
+            job->ready.pop_back();
+            lk.unlock();
+            job->flow->m_Nodes[idx].fn();
+            lk.lock();
+            ++job->done;
+            size_t released = 0;
+            for (size_t s : job->flow->m_Nodes[idx].successors)
+                if (--job->pending[s] == 0) { job->ready.push_back(s); ++released; }
+            if (released > 1 || job->done == job->flow->m_Nodes.size()) m_Cv.notify_all();
+        }
+    }
+
+    void workerLoop()
+    {
+        std::unique_lock<std::mutex> lk(m_Mutex);
+        for (;;) {
+            m_Cv.wait(lk, [&] { return m_Stop || (m_Job && !m_Job->ready.empty()); });
+            if (m_Stop) return;
+            runReady(lk);
+        }
+    }
+
+    std::mutex m_Mutex;
+    std::condition_variable m_Cv;
+    Job* m_Job = nullptr;
+    bool m_Stop = false;
+    std::vector<std::thread> m_Threads;
 };
 
 } // namespace tf

@@ -199,6 +199,11 @@ int trhost_render_graph_stats(uint32_t* num_heaps, uint64_t* bytes_reserved, uin
 int trhost_renderer_times(const char* renderer_name, float* cpu_ms, float* gpu_ms)
 {
     return guarded([&] {
+        if (std::string(renderer_name) == "<frame>") {       // host time of the last frame: recording / submission
+            if (cpu_ms) *cpu_ms = g_Graphic.m_LastRecordMs;
+            if (gpu_ms) *gpu_ms = g_Graphic.m_LastSubmitMs;
+            return;
+        }
         for (IRenderer* r : IRenderer::ms_AllRenderers)
             if (r->m_Name == renderer_name) {
                 if (cpu_ms) *cpu_ms = r->m_CPUFrameTime;

@@ -4,6 +4,9 @@
 // the reference's shader-name strings.
 #include "trhip_internal.h"
 
+#include <chrono>
+#include <cstdlib>
+
 #include <algorithm>
 #include <memory>
 
@@ -89,6 +92,31 @@ void DispatchCtx::emit(const char* kernelName, std::function<int(hipStream_t)> f
 } // namespace trhip
 
 using namespace trhip;
+
+namespace
+{
+// TRHIP_HOST_PROFILE=1: host microseconds spent issuing each kind of command, printed at process exit
+// (diagnostics for the submission cost of a frame; off by default).
+struct HostProfile
+{
+    bool on = getenv("TRHIP_HOST_PROFILE") != nullptr;
+    std::mutex m;
+    std::map<std::string, std::pair<uint64_t, double>> acc;
+    void add(const char* kind, double us)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        auto& e = acc[kind];
+        e.first++; e.second += us;
+    }
+    ~HostProfile()
+    {
+        if (!on) return;
+        for (auto& kv : acc)
+            fprintf(stderr, "[trhip host profile] %-14s calls %8llu  total %10.1f us  avg %6.2f us\n", kv.first.c_str(),
+                    (unsigned long long)kv.second.first, kv.second.second, kv.second.second / (double)kv.second.first);
+    }
+} g_hostProfile;
+}
 
 // ------------------------------------------------------------------------------------------------
 hipEvent_t trhip_device_t::acquireEvent()
@@ -491,6 +519,7 @@ int trhip_cmd_write_buffer(trhip_cmdlist cl, trhip_buffer buf, uint64_t off, con
     cl->ops.push_back({ "", [staged, dst](hipStream_t s) {
         TRHIP_HIP(hipMemcpyAsync(dst, staged->data(), staged->size(), hipMemcpyHostToDevice, s));
         return (int)TRHIP_OK; } });
+    cl->ops.back().kind = "write_buffer";
     return TRHIP_OK;
 }
 
@@ -506,6 +535,7 @@ int trhip_cmd_clear_buffer_u32(trhip_cmdlist cl, trhip_buffer buf, uint32_t valu
     cl->ops.push_back({ "", [p, n, value](hipStream_t s) {
         TRHIP_HIP(hipMemsetD32Async((hipDeviceptr_t)p, (int)value, n, s));
         return (int)TRHIP_OK; } });
+    cl->ops.back().kind = "clear_buffer";
     return TRHIP_OK;
 }
 
@@ -521,12 +551,14 @@ int trhip_cmd_clear_texture_f32(trhip_cmdlist cl, trhip_texture tex, float value
         memcpy(&bits, &value, 4);
         size_t n = (size_t)(tex->totalBytes / 4);
         cl->ops.push_back({ "", [p, n, bits](hipStream_t s) { TRHIP_HIP(hipMemsetD32Async((hipDeviceptr_t)p, (int)bits, n, s)); return (int)TRHIP_OK; } });
+        cl->ops.back().kind = "clear_texture";
     } else {
         _Float16 h = (_Float16)value; // round-to-nearest-even
         uint16_t bits;
         memcpy(&bits, &h, 2);
         size_t n = (size_t)(tex->totalBytes / 2);
         cl->ops.push_back({ "", [p, n, bits](hipStream_t s) { TRHIP_HIP(hipMemsetD16Async((hipDeviceptr_t)p, bits, n, s)); return (int)TRHIP_OK; } });
+        cl->ops.back().kind = "clear_texture";
     }
     return TRHIP_OK;
 }
@@ -541,6 +573,7 @@ int trhip_cmd_copy_buffer(trhip_cmdlist cl, trhip_buffer dst, uint64_t dstOff, t
     const void* sp = (const char*)src->ptr + srcOff;
     cl->hold(dst); cl->hold(src);
     cl->ops.push_back({ "", [d, sp, bytes](hipStream_t s) { TRHIP_HIP(hipMemcpyAsync(d, sp, (size_t)bytes, hipMemcpyDeviceToDevice, s)); return (int)TRHIP_OK; } });
+    cl->ops.back().kind = "copy_buffer";
     return TRHIP_OK;
 }
 
@@ -549,6 +582,7 @@ int trhip_cmd_host_callback(trhip_cmdlist cl, trhip_host_fn fn, void* user)
     TRHIP_RECORDING(cl);
     if (!fn) return fail(TRHIP_ERR_INVALID, "host_callback: null function");
     cl->ops.push_back({ "", [fn, user](hipStream_t s) { fn(user, (void*)s); return (int)TRHIP_OK; } });
+    cl->ops.back().kind = "host_callback";
     return TRHIP_OK;
 }
 
@@ -564,6 +598,7 @@ int trhip_cmd_copy_texture(trhip_cmdlist cl, trhip_texture dst, trhip_texture sr
     const uint64_t bytes = src->totalBytes;
     cl->hold(dst); cl->hold(src);
     cl->ops.push_back({ "", [d, sp, bytes](hipStream_t s) { TRHIP_HIP(hipMemcpyAsync(d, sp, (size_t)bytes, hipMemcpyDeviceToDevice, s)); return (int)TRHIP_OK; } });
+    cl->ops.back().kind = "copy_texture";
     return TRHIP_OK;
 }
 
@@ -623,6 +658,7 @@ int trhip_cmd_begin_timer(trhip_cmdlist cl, trhip_timer t)
     TRHIP_RECORDING(cl);
     if (!t) return fail(TRHIP_ERR_INVALID, "timer is null");
     cl->ops.push_back({ "", [t](hipStream_t s) { TRHIP_HIP(hipEventRecord(t->e0, s)); t->began = true; t->ended = false; return (int)TRHIP_OK; } });
+    cl->ops.back().kind = "timer";
     return TRHIP_OK;
 }
 
@@ -631,6 +667,7 @@ int trhip_cmd_end_timer(trhip_cmdlist cl, trhip_timer t)
     TRHIP_RECORDING(cl);
     if (!t) return fail(TRHIP_ERR_INVALID, "timer is null");
     cl->ops.push_back({ "", [t](hipStream_t s) { TRHIP_HIP(hipEventRecord(t->e1, s)); t->ended = true; return (int)TRHIP_OK; } });
+    cl->ops.back().kind = "timer";
     return TRHIP_OK;
 }
 
@@ -663,7 +700,9 @@ int trhip_queue_execute(trhip_device dev, const trhip_cmdlist* lists, uint32_t n
             const bool prof = dev->profiling && !op.name.empty();
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (prof) { e0 = dev->acquireEvent(); e1 = dev->acquireEvent(); TRHIP_HIP(hipEventRecord(e0, dev->stream)); }
+            const auto h0 = g_hostProfile.on ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point{};
             int rc = op.fn(dev->stream);
+            if (g_hostProfile.on) g_hostProfile.add(op.kind, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count());
             if (rc != TRHIP_OK) return rc;
             if (prof) { TRHIP_HIP(hipEventRecord(e1, dev->stream)); dev->pending.push_back({ op.name, e0, e1 }); }
         }

@@ -119,6 +119,7 @@ struct Op
 {
     std::string name;                       // profile key ("" = not profiled)
     std::function<int(hipStream_t)> fn;
+    const char* kind = "dispatch";          // what the op is, for the host-side submission profile (TRHIP_HOST_PROFILE=1)
 };
 
 } // namespace trhip
