@@ -170,6 +170,7 @@ def main():
     dev = rhi.Device(handle=r.device())
     (i0, i1), n_local, n_total = build_shard(spec, rank, world, r, threads=min(8, host_threads()))
     r.set_culling(args.flags)
+    r.set_gpu_timers(False)          # the per-renderer timer queries are instrumentation (2 timestamp packets each)
     r.upload_depth(depth)
     gather = None
     if dist is not None:

@@ -44,6 +44,9 @@ int  trhost_set_culling(int frustum, int occlusion, int cone, int freeze_culling
 /* Capacity of the amplification-record buffer (kMaxThreadGroupsPerDimension = 65535 in the reference)
  * and the per-resource cap of the render graph (1 GB in the reference); 0 keeps the current value. */
 int  trhost_set_limits(uint32_t max_meshlet_groups, uint64_t max_transient_resource_bytes);
+/* Per-renderer GPU timer queries (RenderGraph.cpp:262-281, read back by trhost_renderer_times).  On by default like
+ * the reference; each query is two timestamped barrier packets on the stream. */
+int  trhost_set_gpu_timers(int enable);
 
 /* Depth image the next frames' GenerateHZB will consume (stand-in for the rasteriser). */
 int  trhost_upload_depth(const float* depth, uint32_t width, uint32_t height);

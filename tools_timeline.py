@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Print the kernel timeline of the last frames from a rocprofv3 --kernel-trace CSV (start/end relative
+to the frame's first kernel, stream/queue id), to see what overlaps.  usage: tools_timeline.py trace.csv [frames]"""
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+nframes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+k = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?"), r.get("Stream_Id", "?")) for r in rows]
+k.sort()
+# a frame starts at each instanceClassifyKernel<0>
+starts = [i for i, x in enumerate(k) if "instanceClassifyKernel<0>" in x[2] or "instanceClassifyKernelILi0" in x[2]]
+if len(starts) < nframes + 1:
+    print("not enough frames", len(starts)); sys.exit(0)
+a, b = starts[-nframes - 1], starts[-1]
+t0 = k[a][0]
+for s, e, name, q, st in k[a:b]:
+    short = name.split("(")[0][-60:]
+    print(f"{(s - t0) / 1e3:9.1f} {(e - t0) / 1e3:9.1f}  dur {(e - s) / 1e3:7.1f} us  q{q} s{st}  {short}")
+print("frame span us:", (k[b][0] - t0) / 1e3 / nframes)

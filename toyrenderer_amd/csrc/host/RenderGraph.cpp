@@ -181,13 +181,18 @@ tf::Task RenderGraph::AddRenderer(IRenderer* renderer)
         const auto t0 = std::chrono::steady_clock::now();
         {
             SCOPED_COMMAND_LIST(pass.m_CommandList, r->m_Name.c_str());
-            nvrhi::TimerQueryHandle& query = r->m_FrameTimerQuery[g_Graphic.m_FrameCounter % 2];
-            if (!query) query = g_Graphic.m_NVRHIDevice->createTimerQuery();
-            r->m_GPUFrameTime = 1e3f * g_Graphic.m_NVRHIDevice->getTimerQueryTime(query);   // result of 2 frames ago
-            g_Graphic.m_NVRHIDevice->resetTimerQuery(query);
-            pass.m_CommandList->beginTimerQuery(query);
-            r->Render(pass.m_CommandList, *this);
-            pass.m_CommandList->endTimerQuery(query);
+            if (g_Graphic.m_bEnableGPUTimers) {
+                nvrhi::TimerQueryHandle& query = r->m_FrameTimerQuery[g_Graphic.m_FrameCounter % 2];
+                if (!query) query = g_Graphic.m_NVRHIDevice->createTimerQuery();
+                r->m_GPUFrameTime = 1e3f * g_Graphic.m_NVRHIDevice->getTimerQueryTime(query);   // result of 2 frames ago
+                g_Graphic.m_NVRHIDevice->resetTimerQuery(query);
+                pass.m_CommandList->beginTimerQuery(query);
+                r->Render(pass.m_CommandList, *this);
+                pass.m_CommandList->endTimerQuery(query);
+            } else {
+                r->m_GPUFrameTime = 0.0f;
+                r->Render(pass.m_CommandList, *this);
+            }
         }
         r->m_CPUFrameTime = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         tl_CurrentThreadPassID = kInvalidPassID;

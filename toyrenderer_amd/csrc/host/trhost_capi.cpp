@@ -113,6 +113,11 @@ int trhost_set_culling(int frustum, int occlusion, int cone, int freeze_culling_
     });
 }
 
+int trhost_set_gpu_timers(int enable)
+{
+    return guarded([&] { g_Graphic.m_bEnableGPUTimers = enable != 0; });
+}
+
 int trhost_set_limits(uint32_t max_meshlet_groups, uint64_t max_transient_resource_bytes)
 {
     return guarded([&] {

@@ -540,21 +540,28 @@ __global__ __launch_bounds__(256) void shardConcatKernel(ShardUnpackArgs a)
     }
 }
 
-// Launches the ordered-list build (count -> scan -> expand) over a mask array.
-void emitListBuild(const trhip::DispatchCtx& ctx, const MeshletCullArgs& a, const char* prefix)
+// Launches the ordered-list build (count -> scan -> expand) over a mask array.  side: on the device's side
+// stream -- nothing later in a frame consumes the list, so it overlaps the passes that follow (HZB build,
+// late phase); the back end joins it before any command that touches the same buffers and at the end of
+// the submission (trhip_internal.h).
+void emitListBuild(const trhip::DispatchCtx& ctx, const MeshletCullArgs& a, const char* prefix, bool side, const void* argsBase)
 {
+    auto emit = [&](const std::string& name, std::function<int(hipStream_t)> fn) {
+        if (side) ctx.emitSide(name.c_str(), std::move(fn), { argsBase, a.visMask, a.visibleList, a.drawArgs });
+        else ctx.emit(name.c_str(), std::move(fn));
+    };
     const uint32_t needBlocks = (a.maxBatches + kWaves - 1) / kWaves;
     uint32_t gridSmall = ctx.computeUnits() * 8u;      // count / expand: light kernels, one wave per 64 groups
     if (gridSmall > needBlocks) gridSmall = needBlocks;
     if (gridSmall == 0) gridSmall = 1;
     const std::string p = prefix;
-    ctx.emit((p + "count").c_str(), [a, gridSmall](hipStream_t s) {
+    emit(p + "count", [a, gridSmall](hipStream_t s) {
         hipLaunchKernelGGL(visCountKernel, dim3(gridSmall), dim3(kBlock), 0, s, a);
         return trhip::launchStatus("visCountKernel"); });
-    ctx.emit((p + "scan").c_str(), [a](hipStream_t s) {
+    emit(p + "scan", [a](hipStream_t s) {
         hipLaunchKernelGGL(visScanKernel, dim3(1), dim3(1024), 0, s, a);
         return trhip::launchStatus("visScanKernel"); });
-    ctx.emit((p + "expand").c_str(), [a, gridSmall](hipStream_t s) {
+    emit(p + "expand", [a, gridSmall](hipStream_t s) {
         hipLaunchKernelGGL(visExpandKernel, dim3(gridSmall), dim3(kBlock), 0, s, a);
         return trhip::launchStatus("visExpandKernel"); });
 }
@@ -627,7 +634,8 @@ int recordASMain(trhip::DispatchCtx& ctx)
         a.perm = a.permHeader + 64;
     }
     a.maxBatches = (a.recordCapacity + kBatch - 1) / kBatch;
-    a.batchSum = (uint32_t*)ctx.scratch((size_t)a.maxBatches * 4);
+    a.batchSum = (uint32_t*)(a.recordCapacity >= (1u << 19) ? ctx.scratchSide((size_t)a.maxBatches * 4)   // only the list build uses it
+                                                            : ctx.scratch((size_t)a.maxBatches * 4));
     TRHIP_REQUIRE(a.batchSum, "%s: scratch allocation failed", ctx.shaderName);
 
     // Persistent grid: the group count lives on the device (indirect), so launch enough
@@ -651,7 +659,9 @@ int recordASMain(trhip::DispatchCtx& ctx)
         default: launchCull<true, true, true>(a, grid, s); break;
         }
         return trhip::launchStatus("meshletCullKernel"); });
-    emitListBuild(ctx, a, "");
+    // The side stream costs two events and two cross-stream waits per run (~20 us of host time): worth it
+    // when the list build is long (>= 2^19 groups of capacity), not for small passes.
+    emitListBuild(ctx, a, "", a.recordCapacity >= (1u << 19), ctx.argsBuffer->ptr);
     return TRHIP_OK;
 }
 
@@ -751,7 +761,7 @@ int recordUnpackShards(trhip::DispatchCtx& ctx)
     for (uint32_t s = 0; s < kMaxPassSlots; ++s)
         if (a.records[s]) {
             const char prefix[] = { 's', 'l', 'o', 't', (char)('0' + s), '_', 0 };
-            emitListBuild(ctx, lists[s], prefix);
+            emitListBuild(ctx, lists[s], prefix, false, nullptr);
         }
     return TRHIP_OK;
 }

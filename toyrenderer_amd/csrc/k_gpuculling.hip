@@ -66,6 +66,7 @@ constexpr uint32_t kTilesPerAxis = 32;
 constexpr uint32_t kNumTiles = kTilesPerAxis * kTilesPerAxis;
 constexpr uint32_t kTileReplicas = 32;            // counters are replicated (blockIdx % 32) to spread the atomics
 constexpr uint32_t kPermHeaderWords = 64;
+constexpr uint32_t kMinBinnedEntries = 4096;      // below this many list entries the processing order is left alone (device-side test)
 
 // Which 1/32 x 1/32 screen tile the instance's centre projects to.  Scheduling heuristic only
 // (approximate reciprocal, no exactness requirement): it never influences an output value.
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void instanceClassifyKernel(InstanceCullArg
     if (t < n) word = classify<LATE>(a, a.ids[t], &tile);
 
     const uint32_t g = (word & kWordSubmit) ? (word & kGroupMask) : 0u;
-    if (g != 0) {
+    if (g != 0 && n >= kMinBinnedEntries) {
         atomicAdd(&a.tileCount[tile * kTileReplicas + (blockIdx.x % kTileReplicas)], g);   // histogram of groups per screen tile
         a.tileOf[t] = (uint16_t)tile;
     }
@@ -260,11 +261,11 @@ __global__ __launch_bounds__(1024) void instanceScanKernel(InstanceCullArgs a)
         if (!LATE) *a.lateCount = baseLate + (uint32_t)s_carryLS;   // :165
         // The tile-sorted processing order is published only when every group is emitted (no Q2 drop,
         // pass started from a cleared counter) and fits: then it is a permutation of [0, X).
-        a.permHeader[0] = (baseX == 0 && X < a.maxGroups && X <= a.permCapacity) ? 1u : 0u;
+        a.permHeader[0] = (n >= kMinBinnedEntries && baseX == 0 && X < a.maxGroups && X <= a.permCapacity) ? 1u : 0u;
         a.permHeader[1] = X;
     }
     // tile histogram -> exclusive prefix (cursors for the emit kernel); thread = tile, its replicas are contiguous
-    {
+    if (n >= kMinBinnedEntries) {
         __syncthreads();
         const uint32_t lane = tid & 63u, wave = tid >> 6;
         uint32_t rep[kTileReplicas];
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(kBlock) void instanceEmitKernel(InstanceCullArgs a)
         MeshletAmplificationData rec = { id, lod, i * kNumThreadsPerWave };
         a.records[off + i] = rec;
     }
-    if (groups != 0) {                                                              // slot range in the tile-sorted order
+    if (groups != 0 && n >= kMinBinnedEntries) {                                    // slot range in the tile-sorted order
         const uint32_t p = atomicAdd(&a.tileCount[(uint32_t)a.tileOf[t] * kTileReplicas + (blockIdx.x % kTileReplicas)], groups);
         for (uint32_t i = 0; i < groups; ++i)
             if (p + i < a.permCapacity) a.perm[p + i] = off + i;
@@ -439,10 +440,8 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
         a.perm = a.permHeader + kPermHeaderWords;
         a.permCapacity = a.maxGroups;
     }
-    {
-        uint32_t* tc = a.tileCount;
-        ctx.emit("clear_tiles", [tc](hipStream_t s) { TRHIP_HIP(hipMemsetAsync(tc, 0, kNumTiles * kTileReplicas * 4, s)); return (int)TRHIP_OK; });
-    }
+    rc = ctx.cl->recordClearWords(a.tileCount, kNumTiles * kTileReplicas, 0);   // joins the pass's other clears in one launch
+    if (rc != TRHIP_OK) return rc;
 
     ctx.emit("classify", [a](hipStream_t s) {
         hipLaunchKernelGGL(instanceClassifyKernel<LATE>, dim3(a.numBlocks), dim3(kBlock), 0, s, a);

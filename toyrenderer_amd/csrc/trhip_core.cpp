@@ -89,6 +89,14 @@ void DispatchCtx::emit(const char* kernelName, std::function<int(hipStream_t)> f
     cl->ops.push_back({ std::move(n), std::move(fn) });
 }
 
+void DispatchCtx::emitSide(const char* kernelName, std::function<int(hipStream_t)> fn, std::initializer_list<const void*> touched) const
+{
+    emit(kernelName, std::move(fn));
+    if (!cl->dev->sideStream) return;                  // no side stream: plain in-order op
+    cl->ops.back().lane = 1;
+    for (const void* p : touched) if (p) cl->ops.back().touched.push_back(p);
+}
+
 } // namespace trhip
 
 using namespace trhip;
@@ -144,17 +152,27 @@ int trhip_device_t::drainProfile()
     return TRHIP_OK;
 }
 
-void* trhip_cmdlist_t::scratchAlloc(size_t bytes)
+static void* arenaAlloc(std::vector<trhip_cmdlist_t::ScratchBlock>& arena, int deviceIndex, size_t bytes)
 {
     bytes = (bytes + 255) & ~size_t(255);
     if (bytes == 0) bytes = 256;
-    for (ScratchBlock& b : scratch)
+    for (trhip_cmdlist_t::ScratchBlock& b : arena)
         if (b.bytes - b.used >= bytes) { void* p = (char*)b.ptr + b.used; b.used += bytes; return p; }
     size_t blockBytes = std::max(bytes, size_t(1) << 20);
     void* p = nullptr;
-    if (hipSetDevice(dev->index) != hipSuccess || hipMalloc(&p, blockBytes) != hipSuccess) return nullptr;
-    scratch.push_back({ p, blockBytes, bytes });
+    if (hipSetDevice(deviceIndex) != hipSuccess || hipMalloc(&p, blockBytes) != hipSuccess) return nullptr;
+    arena.push_back({ p, blockBytes, bytes });
     return p;
+}
+
+void* trhip_cmdlist_t::scratchAlloc(size_t bytes) { return arenaAlloc(scratch, dev->index, bytes); }
+void* trhip_cmdlist_t::scratchAllocSide(size_t bytes) { return arenaAlloc(sideScratch, dev->index, bytes); }
+
+int trhip_device_t::syncAll()
+{
+    TRHIP_HIP(hipStreamSynchronize(stream));
+    if (sideStream) TRHIP_HIP(hipStreamSynchronize(sideStream));
+    return TRHIP_OK;
 }
 
 void trhip_cmdlist_t::resetRecording()
@@ -165,11 +183,58 @@ void trhip_cmdlist_t::resetRecording()
     heldBuffers.clear();
     heldTextures.clear();
     markers.clear();
+    useMarks.clear();
+    openClearBatch.reset();
+    openClearOp = SIZE_MAX;
     for (ScratchBlock& b : scratch) b.used = 0;
+    for (ScratchBlock& b : sideScratch) b.used = 0;
 }
 
-void trhip_cmdlist_t::hold(trhip_buffer_t* b) { if (b) { trhip_buffer_retain(b); heldBuffers.push_back(b); } }
-void trhip_cmdlist_t::hold(trhip_texture_t* t) { if (t) { trhip_texture_retain(t); heldTextures.push_back(t); } }
+namespace
+{
+struct ClearKernelArgs { void* ptr[trhip_cmdlist_t::ClearBatch::kMax]; uint64_t words[trhip_cmdlist_t::ClearBatch::kMax]; uint32_t value[trhip_cmdlist_t::ClearBatch::kMax]; uint32_t count; };
+
+__global__ __launch_bounds__(256) void multiClearKernel(ClearKernelArgs a)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint32_t k = 0; k < a.count; ++k) {
+        uint32_t* p = (uint32_t*)a.ptr[k];
+        const uint32_t v = a.value[k];
+        for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < a.words[k]; i += stride) p[i] = v;
+    }
+}
+}
+
+int trhip_cmdlist_t::recordClearWords(void* ptr, uint64_t words, uint32_t value)
+{
+    if (words == 0) return TRHIP_OK;
+    if (!(openClearBatch && openClearOp == ops.size() - 1 && openClearBatch->count < ClearBatch::kMax)) {
+        openClearBatch = std::make_shared<ClearBatch>();
+        std::shared_ptr<ClearBatch> b = openClearBatch;
+        const uint32_t cus = dev->computeUnits;
+        ops.push_back({ "", [b, cus](hipStream_t s) {
+            ClearKernelArgs a;
+            uint64_t most = 0;
+            a.count = b->count;
+            for (uint32_t k = 0; k < b->count; ++k) { a.ptr[k] = b->ptr[k]; a.words[k] = b->words[k]; a.value[k] = b->value[k]; most = std::max(most, b->words[k]); }
+            uint64_t grid = (most + 1023u) / 1024u;                      // ~4 words per thread for the largest range
+            if (grid > (uint64_t)cus * 8u) grid = (uint64_t)cus * 8u;
+            if (grid == 0) grid = 1;
+            hipLaunchKernelGGL(multiClearKernel, dim3((uint32_t)grid), dim3(256), 0, s, a);
+            return trhip::launchStatus("multiClearKernel"); } });
+        ops.back().kind = "clear_buffer";
+        openClearOp = ops.size() - 1;
+    }
+    ClearBatch& b = *openClearBatch;
+    b.ptr[b.count] = ptr; b.words[b.count] = words; b.value[b.count] = value;
+    ++b.count;
+    return TRHIP_OK;
+}
+
+// Every command holds the resources it uses before it is recorded: the one place that notes WHICH command
+// uses WHAT, for ordering against side-stream work on the same memory at execute time.
+void trhip_cmdlist_t::hold(trhip_buffer_t* b, size_t op) { if (b) { use(b->ptr, op == SIZE_MAX ? ops.size() : op); trhip_buffer_retain(b); heldBuffers.push_back(b); } }
+void trhip_cmdlist_t::hold(trhip_texture_t* t) { if (t) { use(t->ptr, ops.size()); trhip_texture_retain(t); heldTextures.push_back(t); } }
 
 // ------------------------------------------------------------------------------------------------
 extern "C" {
@@ -204,6 +269,11 @@ static int deviceCreate(int index, void* stream, bool external, trhip_device* ou
         TRHIP_HIP(hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking));
         dev->ownsStream = true;
     }
+    if (!getenv("TRHIP_NO_SIDE_STREAM")) {             // see trhip_device_t::sideStream
+        TRHIP_HIP(hipStreamCreateWithFlags(&dev->sideStream, hipStreamNonBlocking));
+        TRHIP_HIP(hipEventCreateWithFlags(&dev->evFork, hipEventDisableTiming));
+        for (hipEvent_t& e : dev->runDone) TRHIP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     *out = dev.release();
     return TRHIP_OK;
 }
@@ -215,9 +285,12 @@ void trhip_device_destroy(trhip_device dev)
 {
     if (!dev) return;
     (void)hipSetDevice(dev->index);
-    (void)hipStreamSynchronize(dev->stream);
+    (void)dev->syncAll();
     (void)dev->drainProfile();
     for (hipEvent_t e : dev->eventPool) (void)hipEventDestroy(e);
+    if (dev->sideStream) { (void)hipStreamSynchronize(dev->sideStream); (void)hipStreamDestroy(dev->sideStream); }
+    if (dev->evFork) (void)hipEventDestroy(dev->evFork);
+    for (hipEvent_t e : dev->runDone) if (e) (void)hipEventDestroy(e);
     if (dev->ownsStream) (void)hipStreamDestroy(dev->stream);
     delete dev;
 }
@@ -226,8 +299,7 @@ int trhip_device_wait_idle(trhip_device dev)
 {
     if (!dev) return fail(TRHIP_ERR_INVALID, "device is null");
     TRHIP_HIP(hipSetDevice(dev->index));
-    TRHIP_HIP(hipStreamSynchronize(dev->stream));
-    return TRHIP_OK;
+    return dev->syncAll();
 }
 
 int trhip_device_info(trhip_device dev, uint32_t* cus, uint32_t* wave, uint64_t* mem)
@@ -420,7 +492,8 @@ int trhip_texture_mip_info(trhip_texture t, uint32_t mip, uint32_t* w, uint32_t*
 static int syncCopy(trhip_device_t* dev, void* dst, const void* src, uint64_t bytes, hipMemcpyKind kind)
 {
     TRHIP_HIP(hipSetDevice(dev->index));
-    TRHIP_HIP(hipStreamSynchronize(dev->stream));
+    int rc = dev->syncAll();
+    if (rc != TRHIP_OK) return rc;
     TRHIP_HIP(hipMemcpy(dst, src, (size_t)bytes, kind));
     return TRHIP_OK;
 }
@@ -473,9 +546,10 @@ void trhip_cmd_release(trhip_cmdlist cl)
 {
     if (!cl) return;
     (void)hipSetDevice(cl->dev->index);
-    (void)hipStreamSynchronize(cl->dev->stream); // recorded ops may still reference scratch
+    (void)cl->dev->syncAll();                    // recorded ops may still reference scratch
     cl->resetRecording();
     for (auto& b : cl->scratch) (void)hipFree(b.ptr);
+    for (auto& b : cl->sideScratch) (void)hipFree(b.ptr);
     delete cl;
 }
 
@@ -494,6 +568,8 @@ int trhip_cmd_close(trhip_cmdlist cl)
     if (!cl->open) return fail(TRHIP_ERR_STATE, "cmd_close: not open");
     if (!cl->markers.empty()) return fail(TRHIP_ERR_STATE, "cmd_close: %zu marker(s) still open", cl->markers.size());
     cl->open = false;
+    // by command index (a clear merged into an earlier launch is noted against that launch)
+    std::stable_sort(cl->useMarks.begin(), cl->useMarks.end(), [](const trhip_cmdlist_t::UseMark& a, const trhip_cmdlist_t::UseMark& b) { return a.op < b.op; });
     return TRHIP_OK;
 }
 
@@ -529,14 +605,9 @@ int trhip_cmd_clear_buffer_u32(trhip_cmdlist cl, trhip_buffer buf, uint32_t valu
     if (!buf) return fail(TRHIP_ERR_INVALID, "clear_buffer: null buffer");
     if (!buf->ptr) return fail(TRHIP_ERR_STATE, "clear_buffer(%s): no memory bound", buf->name.c_str());
     if (buf->byteSize % 4) return fail(TRHIP_ERR_INVALID, "clear_buffer(%s): size not a multiple of 4", buf->name.c_str());
-    void* p = buf->ptr;
-    size_t n = (size_t)(buf->byteSize / 4);
-    cl->hold(buf);
-    cl->ops.push_back({ "", [p, n, value](hipStream_t s) {
-        TRHIP_HIP(hipMemsetD32Async((hipDeviceptr_t)p, (int)value, n, s));
-        return (int)TRHIP_OK; } });
-    cl->ops.back().kind = "clear_buffer";
-    return TRHIP_OK;
+    const bool merges = cl->openClearBatch && cl->openClearOp == cl->ops.size() - 1 && cl->openClearBatch->count < trhip_cmdlist_t::ClearBatch::kMax;
+    cl->hold(buf, merges ? cl->openClearOp : cl->ops.size());
+    return cl->recordClearWords(buf->ptr, buf->byteSize / 4, value);
 }
 
 int trhip_cmd_clear_texture_f32(trhip_cmdlist cl, trhip_texture tex, float value)
@@ -691,23 +762,68 @@ int trhip_queue_execute(trhip_device dev, const trhip_cmdlist* lists, uint32_t n
     if (!dev || (n && !lists)) return fail(TRHIP_ERR_INVALID, "queue_execute: null argument");
     TRHIP_HIP(hipSetDevice(dev->index));
     std::lock_guard<std::mutex> lock(dev->mutex);
+    bool inRun = false;
+    std::vector<const void*> runTouched;
+    auto endRun = [&]() -> int {                       // the side stream's current run is complete: publish its event
+        if (!inRun) return TRHIP_OK;
+        inRun = false;
+        const uint64_t id = ++dev->sideRunCounter;
+        const uint32_t slot = (uint32_t)(id % trhip_device_t::kSideRuns);
+        if (id > trhip_device_t::kSideRuns && id - trhip_device_t::kSideRuns > dev->mainWaitedUpTo) {
+            TRHIP_HIP(hipStreamWaitEvent(dev->stream, dev->runDone[slot], 0));   // the run that owned this event slot
+            dev->mainWaitedUpTo = id - trhip_device_t::kSideRuns;
+        }
+        TRHIP_HIP(hipEventRecord(dev->runDone[slot], dev->sideStream));
+        for (const void* p : runTouched) dev->sideOwner[p] = id;
+        runTouched.clear();
+        return TRHIP_OK;
+    };
+    auto waitForOwner = [&](const void* ptr) -> int {   // a main-stream command uses `ptr`
+        if (dev->sideOwner.empty()) return TRHIP_OK;
+        auto it = dev->sideOwner.find(ptr);
+        if (it == dev->sideOwner.end() || it->second <= dev->mainWaitedUpTo) return TRHIP_OK;
+        TRHIP_HIP(hipStreamWaitEvent(dev->stream, dev->runDone[it->second % trhip_device_t::kSideRuns], 0));
+        dev->mainWaitedUpTo = it->second;              // the side stream is in order: earlier runs are covered too
+        return TRHIP_OK;
+    };
     for (uint32_t i = 0; i < n; ++i) {
         trhip_cmdlist_t* cl = lists[i];
         if (!cl) return fail(TRHIP_ERR_INVALID, "queue_execute: list %u is null", i);
         if (cl->open) return fail(TRHIP_ERR_STATE, "queue_execute: list %u is still open", i);
         if (cl->dev != dev) return fail(TRHIP_ERR_INVALID, "queue_execute: list %u belongs to another device", i);
-        for (const Op& op : cl->ops) {
+        size_t mark = 0;
+        for (size_t oi = 0; oi < cl->ops.size(); ++oi) {
+            const Op& op = cl->ops[oi];
+            const bool side = op.lane == 1 && dev->sideStream;
+            hipStream_t stream = dev->stream;
+            if (side) {
+                if (!inRun) {                          // fork: the side stream continues from this point of the main stream
+                    TRHIP_HIP(hipEventRecord(dev->evFork, dev->stream));
+                    TRHIP_HIP(hipStreamWaitEvent(dev->sideStream, dev->evFork, 0));
+                    inRun = true;
+                }
+                runTouched.insert(runTouched.end(), op.touched.begin(), op.touched.end());
+                stream = dev->sideStream;
+                while (mark < cl->useMarks.size() && cl->useMarks[mark].op <= oi) ++mark;   // ordered by the fork and by the side stream itself
+            } else {
+                int rc = endRun();
+                if (rc != TRHIP_OK) return rc;
+                for (; mark < cl->useMarks.size() && cl->useMarks[mark].op <= oi; ++mark) {
+                    rc = waitForOwner(cl->useMarks[mark].ptr);
+                    if (rc != TRHIP_OK) return rc;
+                }
+            }
             const bool prof = dev->profiling && !op.name.empty();
             hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (prof) { e0 = dev->acquireEvent(); e1 = dev->acquireEvent(); TRHIP_HIP(hipEventRecord(e0, dev->stream)); }
+            if (prof) { e0 = dev->acquireEvent(); e1 = dev->acquireEvent(); TRHIP_HIP(hipEventRecord(e0, stream)); }
             const auto h0 = g_hostProfile.on ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point{};
-            int rc = op.fn(dev->stream);
+            int rc = op.fn(stream);
             if (g_hostProfile.on) g_hostProfile.add(op.kind, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count());
             if (rc != TRHIP_OK) return rc;
-            if (prof) { TRHIP_HIP(hipEventRecord(e1, dev->stream)); dev->pending.push_back({ op.name, e0, e1 }); }
+            if (prof) { TRHIP_HIP(hipEventRecord(e1, stream)); dev->pending.push_back({ op.name, e0, e1 }); }
         }
     }
-    return TRHIP_OK;
+    return endRun();
 }
 
 // ---- timers / profile ----------------------------------------------------------------------------

@@ -10,8 +10,10 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/trhip.h"
@@ -47,6 +49,19 @@ struct trhip_device_t
     uint32_t computeUnits = 0;
     uint32_t waveSize = 0;
     uint64_t totalMem = 0;
+
+    // Second stream for work whose results nothing later in the frame consumes (the ordered-list build of
+    // a cull pass): it overlaps the passes that follow.  Consecutive side ops form a RUN that ends with an
+    // event; a main-stream command that uses memory a run touched first waits for that run's event
+    // (execute-time check, trhip_queue_execute), and every host-side synchronisation covers both streams.
+    static constexpr uint32_t kSideRuns = 16;
+    hipStream_t sideStream = nullptr;
+    hipEvent_t evFork = nullptr;
+    hipEvent_t runDone[kSideRuns] = {};
+    uint64_t sideRunCounter = 0;               // id of the last finished run (ids start at 1)
+    uint64_t mainWaitedUpTo = 0;               // the main stream is ordered after all runs <= this id
+    std::unordered_map<const void*, uint64_t> sideOwner;   // allocation -> last run that touched it
+    int syncAll();                             // host wait for both streams
 
     std::mutex mutex;
     bool profiling = false;
@@ -120,6 +135,8 @@ struct Op
     std::string name;                       // profile key ("" = not profiled)
     std::function<int(hipStream_t)> fn;
     const char* kind = "dispatch";          // what the op is, for the host-side submission profile (TRHIP_HOST_PROFILE=1)
+    uint8_t lane = 0;                       // 0 main stream, 1 side stream (see DispatchCtx::emitSide)
+    std::vector<const void*> touched;       // side ops: allocations read or written (base pointers)
 };
 
 } // namespace trhip
@@ -136,9 +153,24 @@ struct trhip_cmdlist_t
     struct ScratchBlock { void* ptr; size_t bytes; size_t used; };
     std::vector<ScratchBlock> scratch;
 
+    // Consecutive buffer clears are issued as ONE kernel launch (a frame has ~11 clears of a few bytes
+    // each; a launch costs ~5 us on both sides of the queue).
+    struct ClearBatch { static constexpr uint32_t kMax = 8; void* ptr[kMax]; uint64_t words[kMax]; uint32_t value[kMax]; uint32_t count = 0; };
+    std::shared_ptr<ClearBatch> openClearBatch;    // batch of the LAST op in `ops`, if that op is a clear
+    size_t openClearOp = SIZE_MAX;
+    int recordClearWords(void* ptr, uint64_t words, uint32_t value);
+
+    // Which allocations each command uses (recorded by hold()): checked against the side stream's runs
+    // when the list is executed.
+    struct UseMark { size_t op; const void* ptr; };
+    std::vector<UseMark> useMarks;
+    void use(const void* ptr, size_t op) { if (ptr) useMarks.push_back({ op, ptr }); }
+
     void* scratchAlloc(size_t bytes);       // device memory valid until the list is re-opened/released
+    void* scratchAllocSide(size_t bytes);   // same, from an arena only side-stream ops use (they are in order among themselves)
+    std::vector<ScratchBlock> sideScratch;
     void resetRecording();
-    void hold(trhip_buffer_t* b);
+    void hold(trhip_buffer_t* b, size_t op = SIZE_MAX);     // op: index of the command that uses it (default: the next one)
     void hold(trhip_texture_t* t);
 };
 
@@ -163,7 +195,11 @@ struct DispatchCtx
     const void* constants(uint32_t slot, size_t bytes) const;
     uint32_t computeUnits() const { return cl->dev->computeUnits; }
     void* scratch(size_t bytes) const { return cl->scratchAlloc(bytes); }
+    void* scratchSide(size_t bytes) const { return cl->dev->sideStream ? cl->scratchAllocSide(bytes) : cl->scratchAlloc(bytes); }
     void emit(const char* kernelName, std::function<int(hipStream_t)> fn) const;
+    // Same, on the device's side stream, ordered after everything recorded before it.  `touched`: every
+    // device allocation the op reads or writes that a later command could also use (base pointers).
+    void emitSide(const char* kernelName, std::function<int(hipStream_t)> fn, std::initializer_list<const void*> touched) const;
 };
 
 using RecordFn = int (*)(DispatchCtx&);

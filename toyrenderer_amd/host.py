@@ -19,7 +19,7 @@ HOST_SYMBOLS = [
     "trhost_set_node_transforms", "trhost_set_camera", "trhost_set_culling", "trhost_set_limits", "trhost_upload_depth",
     "trhost_upload_hzb_mip", "trhost_download_hzb_mip", "trhost_hzb_info", "trhost_frame", "trhost_wait_idle",
     "trhost_pass_buffers", "trhost_instance_buffer", "trhost_device", "trhost_render_graph_stats", "trhost_renderer_times",
-    "trhost_heap_sim", "trhost_set_shard_late_exchange",
+    "trhost_heap_sim", "trhost_set_shard_late_exchange", "trhost_set_gpu_timers",
 ]
 
 SHARD_LATE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int)   # trhost_shard_late_fn
@@ -65,6 +65,7 @@ def load() -> C.CDLL:
     L.trhost_device.restype = vp
     L.trhost_render_graph_stats.argtypes = [C.POINTER(u32), C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
     L.trhost_renderer_times.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.trhost_set_gpu_timers.argtypes = [C.c_int]
     L.trhost_set_shard_late_exchange.argtypes = [SHARD_LATE_FN, vp]
     L.trhost_heap_sim.argtypes = [u64, vp, u32, vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
     _lib = L
@@ -166,6 +167,9 @@ class Renderer:
 
     def wait_idle(self):
         _check(load().trhost_wait_idle())
+
+    def set_gpu_timers(self, enable: bool):
+        _check(load().trhost_set_gpu_timers(int(bool(enable))))
 
     def set_shard_late_exchange(self, fn):
         """Multi-GPU hook (include/trhost.h): fn(hip_stream, late_count_ptr, shard_info_ptr, bucket) runs
