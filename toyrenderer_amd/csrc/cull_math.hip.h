@@ -211,6 +211,69 @@ __device__ __forceinline__ bool occlusionResolve(const OccSample& o, uint32_t ro
     return o.accept | (o.depthSphere >= depth);                      // :81
 }
 
+// Footprint-min table of an HZB (built by k_hzb.hip next to the mip chain): entry (x0+1, y0+1) of mip k holds
+// the min over the 2x2 edge-clamped footprint whose origin floor(uv*dim - 0.5) is (x0, y0), x0 in [-1, w-1].
+struct HzbQuad
+{
+    const _Float16* base;
+    uint32_t total;
+    uint32_t offset[16];    // first entry of mip k; row stride w_k + 1
+};
+
+// culling.hlsli:36-82 for the hot kernel: same arithmetic as occlusionPrepare up to the footprint origin, then
+// ONE table entry instead of up to four texels.  The table entry equals the footprint minimum exactly when both
+// bilinear weights of both axes are non-zero; `slow` flags the other lookups (a fractional coordinate that is
+// an exact integer), which the caller resolves with the texel path.
+struct OccQuad
+{
+    bool accept;              // :48-49
+    bool slow;
+    float depthSphere;        // :79
+    uint32_t iq;              // table index (always in range: uv is clamped to [0,1] and NaN-free)
+};
+
+__device__ __forceinline__ OccQuad occlusionPrepareQuad(F3 c, float r, float nearPlane, float P00, float P11, const Hzb& h,
+                                                        const uint32_t* quadOff, uint32_t quadTotal)
+{
+    OccQuad o;
+    o.accept = (c.z - nearPlane) < r;                                // :48-49
+    float crx = c.x * r, cry = c.y * r, crz = c.z * r;               // :53
+    float czr2 = fma_(c.z, c.z, -(r * r));                           // :54
+    float vx = sqrt_(fma_(c.x, c.x, czr2));                          // :56
+    float minx = div_(fma_(vx, c.x, -crz), fma_(vx, c.z, crx));      // :57
+    float maxx = div_(fma_(vx, c.x, crz), fma_(vx, c.z, -crx));      // :58
+    float vy = sqrt_(fma_(c.y, c.y, czr2));                          // :60
+    float miny = div_(fma_(vy, c.y, -crz), fma_(vy, c.z, cry));      // :61
+    float maxy = div_(fma_(vy, c.y, crz), fma_(vy, c.z, -cry));      // :62
+    float ax = clamp_(minx * P00, -1.0f, 1.0f);                      // :64-67
+    float ay = clamp_(miny * P11, -1.0f, 1.0f);
+    float az = clamp_(maxx * P00, -1.0f, 1.0f);
+    float aw = clamp_(maxy * P11, -1.0f, 1.0f);
+    ax = fma_(ax, 0.5f, 0.5f);                                       // :70-71 ClipXYToUV
+    ay = fma_(ay, -0.5f, 0.5f);
+    az = fma_(az, 0.5f, 0.5f);
+    aw = fma_(aw, -0.5f, 0.5f);
+    float width = (az - ax) * (float)h.width;                        // :73
+    float height = (aw - ay) * (float)h.height;                      // :74
+    int mip = hzbLevel(width, height, h.mips);                       // :75
+    float u = (ax + az) * 0.5f, v = (ay + aw) * 0.5f;                // :78
+    uint32_t mw = (h.width >> mip) ? (h.width >> mip) : 1u;
+    uint32_t mh = (h.height >> mip) ? (h.height >> mip) : 1u;
+    float fx = fma_(u, (float)mw, -0.5f);
+    float fy = fma_(v, (float)mh, -0.5f);
+    float flx = __builtin_floorf(fx), fly = __builtin_floorf(fy);
+    const int x0 = (int)flx, y0 = (int)fly;                          // in [-1, mw-1] x [-1, mh-1]
+    // A zero weight drops the second column (row) from the footprint; that only changes the set of texels when the
+    // second column (row) is a different texel after edge clamping, i.e. 0 <= x0 and x0 + 1 <= mw - 1.
+    const bool slowX = !((fx - flx) > 0.0f) & (x0 >= 0) & (x0 + 1 < (int)mw);
+    const bool slowY = !((fy - fly) > 0.0f) & (y0 >= 0) & (y0 + 1 < (int)mh);
+    o.slow = slowX | slowY;
+    uint32_t iq = quadOff[mip] + (uint32_t)(y0 + 1) * (mw + 1u) + (uint32_t)(x0 + 1);
+    o.iq = iq < quadTotal ? iq : quadTotal - 1u;
+    o.depthSphere = div_(nearPlane, c.z - r);                        // :79
+    return o;
+}
+
 // culling.hlsli:36-82; returns true = visible
 __device__ __forceinline__ bool occlusionVisible(F3 c, float r, float nearPlane, float P00, float P11, const Hzb& h)
 {

@@ -19,6 +19,7 @@
 #include "CommonResources.h"
 #include "FFXHelpers.h"
 #include "Graphic.h"
+#include "HostProfile.h"
 #include "GraphicConstants.h"
 #include "RenderGraph.h"
 #include "Scene.h"
@@ -226,6 +227,7 @@ public:
 
     void GPUCulling(nvrhi::CommandListHandle commandList, const RenderGraph& renderGraph, PassSlot slot, bool bLateCull, bool bAlphaMaskPrimitives)
     {
+        HOST_PROFILE_SCOPE("BasePassRenderer::GPUCulling");
         PROFILE_GPU_SCOPED(commandList, "GPU Culling");                       // :306
 
         const uint32_t nbInstances = (uint32_t)(bAlphaMaskPrimitives ? g_Scene->m_AlphaMaskPrimitiveIDs.size() : g_Scene->m_OpaquePrimitiveIDs.size());
@@ -328,6 +330,7 @@ public:
 
     void RenderInstances(nvrhi::CommandListHandle commandList, const RenderGraph& renderGraph, PassSlot slot, bool bIsLateCull, bool bAlphaMaskPrimitives)
     {
+        HOST_PROFILE_SCOPE("BasePassRenderer::RenderInstances");
         PROFILE_GPU_SCOPED(commandList, "Render Instances");                  // :414
 
         const uint32_t nbInstances = (uint32_t)(bAlphaMaskPrimitives ? g_Scene->m_AlphaMaskPrimitiveIDs.size() : g_Scene->m_OpaquePrimitiveIDs.size());

@@ -2,6 +2,8 @@
 // source/Graphic.cpp and source/GraphicRHI.cpp.
 #include "Graphic.h"
 
+#include "HostProfile.h"
+
 #include <chrono>
 
 #include "CommonResources.h"
@@ -154,6 +156,7 @@ void Graphic::ExecuteAllCommandLists()
 
 void Graphic::AddComputePass(const ComputePassParams& p)
 {
+    HOST_PROFILE_SCOPE("Graphic::AddComputePass");
     check(p.m_CommandList);                                                   // Graphic.cpp:895-896
     check(!p.m_ShaderName.empty());
     PROFILE_GPU_SCOPED(p.m_CommandList, p.m_ShaderName.c_str());              // :899

@@ -1,6 +1,8 @@
 // Scene.cpp -- see Scene.h.  Cites are to the reference's source/Scene.cpp.
 #include "Scene.h"
 
+#include "HostProfile.h"
+
 #include <cstring>
 
 #include "Graphic.h"
@@ -96,15 +98,18 @@ void Scene::PostSceneLoad() {}
 
 void Scene::Update()
 {
-    m_View.Update();                                                          // Scene.cpp:475
+    { HOST_PROFILE_SCOPE("Scene::Update view"); m_View.Update(); }           // Scene.cpp:475
 
     tf::Taskflow tf;
-    m_RenderGraph->InitializeForFrame(tf);                                    // :487
+    { HOST_PROFILE_SCOPE("RenderGraph::InitializeForFrame"); m_RenderGraph->InitializeForFrame(tf); }   // :487
     // pass schedule (:491-512): only the passes of the visibility path exist here
-    m_RenderGraph->AddRenderer(g_UpdateInstanceConstsRenderer);
-    m_RenderGraph->AddRenderer(g_GBufferRenderer);
-    m_RenderGraph->Compile();                                                 // :515
-    m_Executor.corun(tf);                                                     // :518
+    {
+        HOST_PROFILE_SCOPE("RenderGraph::AddRenderer x2 (Setup)");
+        m_RenderGraph->AddRenderer(g_UpdateInstanceConstsRenderer);
+        m_RenderGraph->AddRenderer(g_GBufferRenderer);
+    }
+    { HOST_PROFILE_SCOPE("RenderGraph::Compile"); m_RenderGraph->Compile(); }                            // :515
+    { HOST_PROFILE_SCOPE("Executor::corun (Render)"); m_Executor.corun(tf); }                            // :518
 }
 
 void Scene::Shutdown()

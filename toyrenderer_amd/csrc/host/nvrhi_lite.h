@@ -10,6 +10,8 @@
 // aborts like SDL_assert.
 #pragma once
 
+#include "HostProfile.h"
+
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
@@ -305,6 +307,7 @@ public:
     void dispatch(uint32_t gx, uint32_t gy = 1, uint32_t gz = 1)
     {
         std::vector<trhip_binding> b = flatten();
+        HOST_PROFILE_SCOPE("trhip_cmd_dispatch (record)");
         throwIfFailed(trhip_cmd_dispatch(m_Native, m_State.pipeline.c_str(), b.data(), (uint32_t)b.size(),
                                          m_Push.empty() ? nullptr : m_Push.data(), (uint32_t)m_Push.size(), gx, gy, gz), "ICommandList::dispatch");
         m_Push.clear();
@@ -313,6 +316,7 @@ public:
     {
         check(m_State.indirectParams);
         std::vector<trhip_binding> b = flatten();
+        HOST_PROFILE_SCOPE("trhip_cmd_dispatch_indirect (record)");
         throwIfFailed(trhip_cmd_dispatch_indirect(m_Native, m_State.pipeline.c_str(), b.data(), (uint32_t)b.size(),
                                                   m_Push.empty() ? nullptr : m_Push.data(), (uint32_t)m_Push.size(),
                                                   m_State.indirectParams->native(), offsetBytes), "ICommandList::dispatchIndirect");

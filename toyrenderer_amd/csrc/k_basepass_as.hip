@@ -45,6 +45,7 @@ constexpr uint32_t kBlock = 256;
 constexpr uint32_t kWaves = kBlock / 64;
 constexpr uint32_t kBatch = 64;                  // records per wave batch
 constexpr uint32_t kSteps = kBatch / 2;          // two records per wave step
+constexpr uint32_t kSlowCap = 64;                // per wave and batch: lookups deferred to the texel path (see OccQuad::slow)
 
 struct RecordInfo                                 // per-record invariants parked in LDS (96 B)
 {
@@ -63,6 +64,7 @@ struct MeshletCullArgs
     const MeshletData* meshlets;
     const MeshletAmplificationData* records;
     cm::Hzb hzb;
+    cm::HzbQuad quad;                             // footprint-min table of hzb (k_hzb.hip)
     const uint32_t* dispatchArgs;                 // {X,1,1[,validRecords]} read on the device
     uint32_t argsWords;
     uint32_t recordCapacity;
@@ -96,11 +98,12 @@ __device__ __forceinline__ uint32_t groupCount(const MeshletCullArgs& a)
 // Every lane always loads (lanes past the record's end re-read chunk 0): with no exec-masked or
 // conditional loads in the loop the compiler can count outstanding loads exactly and emits partial
 // s_waitcnt vmcnt(N) instead of vmcnt(0).
-struct MeshletRegs { float4 a, b; };
+typedef float v4f __attribute__((ext_vector_type(4)));
+struct MeshletRegs { v4f a, b; };                // kept as two 128-bit register tuples from the load to the first use
 
 __device__ __forceinline__ MeshletRegs loadMeshletChunks(const MeshletData* meshlets, uint32_t base, uint32_t count, uint32_t sub)
 {
-    const float4* p = reinterpret_cast<const float4*>(meshlets + (count ? base : 0u));
+    const v4f* p = reinterpret_cast<const v4f*>(meshlets + (count ? base : 0u));
     const uint32_t nChunks = count * 2u;
     const uint32_t ja = sub < nChunks ? sub : 0u, jb = 32u + sub < nChunks ? 32u + sub : 0u;
     MeshletRegs m;
@@ -126,14 +129,19 @@ __device__ __forceinline__ uint32_t compressEvenBits(unsigned long long x)
     return (uint32_t)x;
 }
 
-#ifdef TR_STAMPS   // diagnostic build only: per-segment cycle shares (never shipped, never timed)
+#if defined(TR_STAMPS) || defined(TR_COUNT_SLOW)   // diagnostic builds only (never shipped, never timed)
 __device__ unsigned long long g_stampSums[8];
+#endif
+#ifdef TR_STAMPS
 #define TR_STAMP(i) do { unsigned long long _t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); stampSum[i] += _t - stampLast; stampLast = _t; } while (0)
 #else
 #define TR_STAMP(i) do {} while (0)
 #endif
 
-template <bool FRUSTUM, bool OCCLUSION, bool CONE>
+// TABLE: resolve the HZB lookup through the footprint-min table (one 2-byte load; the early pass, where the
+// table is rebuilt once per frame behind the instance pass) or through the texels themselves (two texel-pair
+// loads; the late pass, which is small and follows an HZB rebuild).  Same results either way.
+template <bool FRUSTUM, bool OCCLUSION, bool CONE, bool TABLE>
 __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
 {
 #ifdef TR_STAMPS
@@ -143,7 +151,10 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
 #endif
     __shared__ RecordInfo s_recAll[kWaves][kBatch];
     __shared__ uint32_t s_gIdxAll[kWaves][kBatch];
-    __shared__ uint32_t s_mipOff[16];
+    __shared__ uint32_t s_quadOff[16];
+    __shared__ uint32_t s_slowAll[kWaves][kSlowCap];
+    __shared__ uint32_t s_slowCount[kWaves];
+    __shared__ uint32_t s_maskAll[kWaves][kBatch];
 
     const uint32_t G = groupCount(a);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -152,7 +163,10 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
     RecordInfo* s_rec = s_recAll[wave];
     uint32_t* s_gIdx = s_gIdxAll[wave];
 
-    if (tid < 16) s_mipOff[tid] = a.hzb.mipOffset[tid];
+    if (tid < 16) s_quadOff[tid] = TABLE ? a.quad.offset[tid] : a.hzb.mipOffset[tid];   // table offsets / mip offsets (texel path)
+    if (tid < kWaves) s_slowCount[tid] = 0;
+    uint32_t* s_slow = s_slowAll[wave];
+    uint32_t* s_mask = s_maskAll[wave];
     __syncthreads();                                                                 // the only workgroup barrier
 
     // Work decomposition: the record list is cut into SUPER-BATCHES of 64 * numWaves records; inside
@@ -224,8 +238,12 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
 
         TR_STAMP(1);   // prologue
         // ---- main loop: two records per step, meshlet data two steps ahead ----------------------
+        // Slot A strictly before slot B, as in the loop: the wait-count pass merges the loop's entry state with its
+        // back-edge state, and only when both look alike does the wait at the loop top stay partial (vmcnt(2)).
         MeshletRegs slotA = loadMeshletChunks(a.meshlets, s_rec[half].meshletBase, s_rec[half].count, sub);
+        __builtin_amdgcn_sched_barrier(0);
         MeshletRegs slotB = loadMeshletChunks(a.meshlets, s_rec[2 + half].meshletBase, s_rec[2 + half].count, sub);
+        __builtin_amdgcn_sched_barrier(0);
         const bool odd = (sub & 1u) != 0;
         const uint32_t myMeshlet = odd ? 16u + (sub >> 1) : (sub >> 1);             // index inside the group
 
@@ -233,10 +251,14 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
             TR_STAMP(7);   // loop overhead / previous tail
             const uint32_t r = 2 * s + half;                                         // record within the batch
             const RecordInfo& ri = s_rec[r];
+            // The ring slot is consumed HERE as two whole 128-bit tuples.  (Without this the compiler carries the eight
+            // dwords across the loop back-edge one by one, copies some of them at the end of the iteration and has to
+            // drain the prefetch that was issued a moment before: s_waitcnt vmcnt(0) at every loop top.)
+            asm volatile("" : "+v"(slot.a), "+v"(slot.b));
             // complete the (sphere, cone) pair with the neighbour lane
             const float r0 = swapWithNeighbour(odd ? slot.a.x : slot.b.x);
             const float r1 = swapWithNeighbour(slot.b.y), r2 = swapWithNeighbour(slot.b.z), r3 = swapWithNeighbour(slot.b.w);
-            const float4 sphere = odd ? make_float4(r0, r1, r2, r3) : slot.a;
+            const float4 sphere = odd ? make_float4(r0, r1, r2, r3) : make_float4(slot.a.x, slot.a.y, slot.a.z, slot.a.w);
             const uint32_t cone = __float_as_uint(odd ? slot.b.x : r0);
             bool vis = myMeshlet < ri.count;
             const cm::M43 W = { { ri.w[0], ri.w[1], ri.w[2] }, { ri.w[3], ri.w[4], ri.w[5] },
@@ -247,22 +269,17 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
             if (FRUSTUM)
                 vis &= cm::frustumVisible(cv, rad, a.k.m_Frustum.x, a.k.m_Frustum.y, a.k.m_Frustum.z, a.k.m_Frustum.w); // :73
             TR_STAMP(2);   // wait for data + exchange + transform + frustum
+            cm::OccQuad oq;
             cm::OccSample os;
-            uint32_t row0 = 0, row1 = 0;
-            if (OCCLUSION) {                                                                       // :75-88 (Q4)
-                os = cm::occlusionPrepare(cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_mipOff);
-#if defined(TR_EXPERIMENT_ONE_TEXEL)       // timing experiments only (wrong results)
-                row0 = cm::loadTexelPair(a.hzb.base, os.i0);
-                row1 = row0;
-#elif defined(TR_EXPERIMENT_ALIGNED_TEXEL)
-                row0 = cm::loadTexelPair(a.hzb.base, os.i0 & ~1u);
-                row1 = cm::loadTexelPair(a.hzb.base, os.i1 & ~1u);
-#elif defined(TR_EXPERIMENT_NO_TEXEL)
-                row0 = os.i0; row1 = os.i1;
-#else
+            uint32_t footprintBits = 0, row0 = 0, row1 = 0;
+            if (OCCLUSION && TABLE) {                                                              // :75-88 (Q4)
+                oq = cm::occlusionPrepareQuad(cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_quadOff, a.quad.total);
+                footprintBits = reinterpret_cast<const uint16_t*>(a.quad.base)[oq.iq];             // the one 2-byte load of the lookup
+            }
+            if (OCCLUSION && !TABLE) {
+                os = cm::occlusionPrepare(cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_quadOff);
                 row0 = cm::loadTexelPair(a.hzb.base, os.i0);
                 row1 = cm::loadTexelPair(a.hzb.base, os.i1);
-#endif
             }
             TR_STAMP(3);   // occlusion prepare + texel load issue
             {                                                                                      // prefetch step s+2 into this slot (past the
@@ -273,23 +290,98 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
                 vis &= !cm::coneBackfacing(cone, cv, rad, { ri.adj[0], ri.adj[1], ri.adj[2] },
                                            { ri.adj[3], ri.adj[4], ri.adj[5] }, { ri.adj[6], ri.adj[7], ri.adj[8] }, V);
             TR_STAMP(4);   // prefetch issue + cone
-            if (OCCLUSION)
+            if (OCCLUSION && !TABLE)
                 vis &= cm::occlusionResolve(os, row0, row1);
+            if (OCCLUSION && TABLE) {
+                // Issue order: table load -> prefetch -> cone ALU -> first use of the table entry.  vmcnt is in order,
+                // so the entry is awaited with vmcnt(2) while the prefetch stays in flight, and its latency hides under
+                // the cone test.  The empty asm makes the entry "depend" on the cone result: without it the scheduler
+                // converts the entry (and waits for it) before the cone test.
+                if (CONE) {
+                    const uint32_t coneDone = vis ? 1u : 0u;
+                    asm volatile("" : "+v"(footprintBits) : "v"(coneDone));
+                }
+                const float footprintMin = (float)__builtin_bit_cast(_Float16, (uint16_t)footprintBits);
+                const bool visO = oq.accept | (oq.depthSphere >= footprintMin);                    // :81
+                // A lookup whose footprint is NOT the table's (a zero bilinear weight) is only noted here -- LDS
+                // traffic, no memory loads in the branch, so the loop's vmcnt bookkeeping stays exact -- and the
+                // meshlet is re-evaluated with the texel path after the batch (fixups below).  Rare.
+                if (__builtin_expect(__ballot(oq.slow) != 0ull, 0)) {
+                    if (oq.slow) {
+                        const uint32_t idx = atomicAdd(&s_slowCount[wave], 1u);
+                        if (idx < kSlowCap) s_slow[idx] = (r << 5) | myMeshlet;
+                    }
+                }
+                vis &= visO;
+            }
             TR_STAMP(5);   // texel wait + resolve
             const unsigned long long ballot = __ballot(vis);                        // :116,120 WavePrefix/ActiveCountBits
             // even lanes tested meshlets 0-15, odd lanes 16-31: put the bits back in meshlet order
             const uint32_t lo16 = compressEvenBits(ballot), hi16 = compressEvenBits(ballot >> 1);
             const uint32_t mask = half ? ((lo16 >> 16) | (hi16 & 0xFFFF0000u)) : ((lo16 & 0xFFFFu) | (hi16 << 16));
-            if (sub == 0) {
-                const uint32_t g = s_gIdx[r];
-                if (g < G) a.visMask[g] = mask;
-            }
+            if (sub == 0) s_mask[r] = mask;             // LDS: the loop itself issues no stores (they would count in vmcnt on gfx9)
             TR_STAMP(6);   // ballot + mask store
         };
 #pragma unroll 1
         for (uint32_t s = 0; s < nSteps; s += 2) {
             step(slotA, s);
             step(slotB, s + 1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (OCCLUSION && TABLE) {
+            // ---- fixups: meshlets whose occlusion lookup needs the texel path (OccQuad::slow); they patch the
+            //      batch's masks while those are still in LDS ---------------------------------------------------
+            const uint32_t nSlow = s_slowCount[wave];
+#ifdef TR_COUNT_SLOW
+            if (lane == 0) {
+                atomicAdd(&g_stampSums[0], 1ull);                         // batches
+                if (nSlow) atomicAdd(&g_stampSums[1], 1ull);             // batches with fixups
+                atomicAdd(&g_stampSums[2], (unsigned long long)nSlow);   // deferred lookups
+                if (nSlow > kSlowCap) atomicAdd(&g_stampSums[3], 1ull);  // list overflows
+            }
+#endif
+            if (__builtin_expect(nSlow != 0u, 0)) {
+                // exact visibility of meshlet m of batch record r (all tests, texel path for the HZB lookup)
+                auto exactVisible = [&](uint32_t r, uint32_t m) -> bool {
+                    const RecordInfo& ri = s_rec[r];
+                    if (m >= ri.count) return false;
+                    const float4* p = reinterpret_cast<const float4*>(a.meshlets + ri.meshletBase);
+                    const float4 sphere = p[2u * m];
+                    const uint32_t cone = __float_as_uint(p[2u * m + 1u].x);
+                    const cm::M43 W = { { ri.w[0], ri.w[1], ri.w[2] }, { ri.w[3], ri.w[4], ri.w[5] },
+                                        { ri.w[6], ri.w[7], ri.w[8] }, { ri.w[9], ri.w[10], ri.w[11] } };
+                    const cm::F3 cv = cm::toView(cm::mulPoint({ sphere.x, sphere.y, sphere.z }, W), V);
+                    const float rad = sphere.w * ri.maxScale;
+                    bool vis = true;
+                    if (FRUSTUM) vis &= cm::frustumVisible(cv, rad, a.k.m_Frustum.x, a.k.m_Frustum.y, a.k.m_Frustum.z, a.k.m_Frustum.w);
+                    vis &= cm::occlusionVisible(cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb);
+                    if (CONE) vis &= !cm::coneBackfacing(cone, cv, rad, { ri.adj[0], ri.adj[1], ri.adj[2] }, { ri.adj[3], ri.adj[4], ri.adj[5] },
+                                                         { ri.adj[6], ri.adj[7], ri.adj[8] }, V);
+                    return vis;
+                };
+                if (nSlow <= kSlowCap) {                                             // patch single bits
+                    if (lane < nSlow) {
+                        const uint32_t e = s_slow[lane], r = e >> 5, m = e & 31u;
+                        if (exactVisible(r, m)) atomicOr(&s_mask[r], 1u << m);
+                        else atomicAnd(&s_mask[r], ~(1u << m));
+                    }
+                } else {                                                             // list overflow: redo the whole batch exactly
+                    for (uint32_t s = 0; s < nSteps; ++s) {
+                        const uint32_t r = 2 * s + half;
+                        const unsigned long long ballot = __ballot(exactVisible(r, sub));
+                        if (sub == 0) s_mask[r] = half ? (uint32_t)(ballot >> 32) : (uint32_t)ballot;
+                    }
+                }
+                if (lane == 0) s_slowCount[wave] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        // ---- the batch's 64 masks leave in one store (lane l: record l of the batch) ----------------------------
+        {
+            const uint32_t g = s_gIdx[lane];
+            if (g < G && (lane >> 1) < nSteps) a.visMask[g] = s_mask[lane];
         }
     }
 #ifdef TR_STAMPS
@@ -547,7 +639,7 @@ __global__ __launch_bounds__(256) void shardConcatKernel(ShardUnpackArgs a)
 void emitListBuild(const trhip::DispatchCtx& ctx, const MeshletCullArgs& a, const char* prefix, bool side, const void* argsBase)
 {
     auto emit = [&](const std::string& name, std::function<int(hipStream_t)> fn) {
-        if (side) ctx.emitSide(name.c_str(), std::move(fn), { argsBase, a.visMask, a.visibleList, a.drawArgs });
+        if (side) ctx.emitSide(name.c_str(), std::move(fn), { { argsBase, false }, { a.visMask, false }, { a.visibleList, true }, { a.drawArgs, true } });
         else ctx.emit(name.c_str(), std::move(fn));
     };
     const uint32_t needBlocks = (a.maxBatches + kWaves - 1) / kWaves;
@@ -567,9 +659,10 @@ void emitListBuild(const trhip::DispatchCtx& ctx, const MeshletCullArgs& a, cons
 }
 
 template <bool F, bool O, bool C>
-void launchCull(const MeshletCullArgs& a, uint32_t grid, hipStream_t s)
+void launchCull(const MeshletCullArgs& a, uint32_t grid, bool table, hipStream_t s)
 {
-    hipLaunchKernelGGL((meshletCullKernel<F, O, C>), dim3(grid), dim3(kBlock), 0, s, a);
+    if (O && table) hipLaunchKernelGGL((meshletCullKernel<F, O, C, true>), dim3(grid), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((meshletCullKernel<F, O, C, false>), dim3(grid), dim3(kBlock), 0, s, a);
 }
 
 int recordASMain(trhip::DispatchCtx& ctx)
@@ -597,6 +690,10 @@ int recordASMain(trhip::DispatchCtx& ctx)
     memset(&a, 0, sizeof a);
     a.k = *k;
     const bool occlusion = (k->m_CullingFlags & kCullingFlagOcclusionCullingEnable) != 0;
+    // LATE_CULL=1 follows an HZB rebuild and covers only what the early phase rejected: texel path, no table.
+    // Small passes (capacity below 2^19 groups) also take the texel path: the table rebuild is a fixed ~20 us per
+    // frame on the side stream and pays off only when the pass is long (same rule in k_gpuculling.hip).
+    const bool useTable = occlusion && ctx.variant == 0 && records->byteSize / sizeof(MeshletAmplificationData) >= (1u << 19);
     int rc = TRHIP_OK;
     {
         memset(&a.hzb, 0, sizeof a.hzb);
@@ -609,6 +706,13 @@ int recordASMain(trhip::DispatchCtx& ctx)
             a.hzb.base = (const _Float16*)hzb->ptr;
             a.hzb.width = hzb->width; a.hzb.height = hzb->height; a.hzb.mips = hzb->mips;
             for (uint32_t m = 0; m < hzb->mips; ++m) a.hzb.mipOffset[m] = (uint32_t)(hzb->mipOffset[m] / 2);
+            if (useTable) {
+                rc = trhip::hzbQuadEnsure(hzb);
+                if (rc != TRHIP_OK) return rc;
+                a.quad.base = (const _Float16*)hzb->quad;
+                a.quad.total = hzb->quadTotal;
+                for (uint32_t m = 0; m < hzb->mips; ++m) a.quad.offset[m] = hzb->quadOffset[m];
+            }
         }
     }
     if (rc != TRHIP_OK) return rc;
@@ -640,23 +744,30 @@ int recordASMain(trhip::DispatchCtx& ctx)
 
     // Persistent grid: the group count lives on the device (indirect), so launch enough
     // workgroups to fill the chip and let them stride over the chunks.
-    uint32_t blocksPerCU = 3u;                     // measured best (sweep 1..6: 1.00/0.76/0.70/0.72/-/0.74 ms); up to 6 fit (25.6 KB LDS each)
+    uint32_t blocksPerCU = 4u;                     // measured best with the table path (3/4/5: 0.900/0.880/0.885 ms per frame); up to 6 fit
     if (const char* e = getenv("TRHIP_AS_BLOCKS_PER_CU")) blocksPerCU = (uint32_t)atoi(e) ? (uint32_t)atoi(e) : blocksPerCU;   // tuning experiments
     uint32_t grid = ctx.computeUnits() * blocksPerCU;
     const uint32_t needBlocks = (a.maxBatches + kWaves - 1) / kWaves;
     if (grid > needBlocks) grid = needBlocks;
     if (grid == 0) grid = 1;
     const uint32_t flags = k->m_CullingFlags & 7u;
-    ctx.emit("cull", [a, grid, flags](hipStream_t s) {
+    trhip_texture_t* quadOwner = useTable ? hzb : nullptr;
+    const bool table = useTable;
+    if (quadOwner) ctx.cl->use(quadOwner->quad, ctx.cl->ops.size(), false);     // the kernel reads the table: ordered after a side-stream rebuild
+    ctx.emit("cull", [a, grid, flags, quadOwner, table](hipStream_t s) {
+        if (quadOwner && !quadOwner->quadValid) {          // the HZB was written since its table was built (upload, clear, copy)
+            int brc = trhip::hzbQuadLaunchBuild(quadOwner, s);
+            if (brc != TRHIP_OK) return brc;
+        }
         switch (flags) {
-        case 0: launchCull<false, false, false>(a, grid, s); break;
-        case 1: launchCull<true, false, false>(a, grid, s); break;
-        case 2: launchCull<false, true, false>(a, grid, s); break;
-        case 3: launchCull<true, true, false>(a, grid, s); break;
-        case 4: launchCull<false, false, true>(a, grid, s); break;
-        case 5: launchCull<true, false, true>(a, grid, s); break;
-        case 6: launchCull<false, true, true>(a, grid, s); break;
-        default: launchCull<true, true, true>(a, grid, s); break;
+        case 0: launchCull<false, false, false>(a, grid, table, s); break;
+        case 1: launchCull<true, false, false>(a, grid, table, s); break;
+        case 2: launchCull<false, true, false>(a, grid, table, s); break;
+        case 3: launchCull<true, true, false>(a, grid, table, s); break;
+        case 4: launchCull<false, false, true>(a, grid, table, s); break;
+        case 5: launchCull<true, false, true>(a, grid, table, s); break;
+        case 6: launchCull<false, true, true>(a, grid, table, s); break;
+        default: launchCull<true, true, true>(a, grid, table, s); break;
         }
         return trhip::launchStatus("meshletCullKernel"); });
     // The side stream costs two events and two cross-stream waits per run (~20 us of host time): worth it
@@ -774,7 +885,7 @@ trhip::ShaderRegistrar r2("basepass_AS_Main_cull", recordASMain, 0);
 
 } // namespace
 
-#ifdef TR_STAMPS
+#if defined(TR_STAMPS) || defined(TR_COUNT_SLOW)
 extern "C" int trhip_debug_read_stamps(unsigned long long* out, int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stampSums), sizeof(unsigned long long) * 8) != hipSuccess) return -1;

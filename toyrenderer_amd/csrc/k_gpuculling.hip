@@ -442,6 +442,12 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
     }
     rc = ctx.cl->recordClearWords(a.tileCount, kNumTiles * kTileReplicas, 0);   // joins the pass's other clears in one launch
     if (rc != TRHIP_OK) return rc;
+    // The early meshlet cull that follows this pass resolves its HZB lookups through the footprint-min table of
+    // this same HZB (k_hzb.hip): bring the table up to date on the side stream while the instance pass runs.
+    if (!LATE && occlusion && a.maxGroups >= (1u << 19)) {                         // the rule of recordASMain (k_basepass_as.hip)
+        rc = trhip::hzbQuadEmitBuild(ctx, hzb);
+        if (rc != TRHIP_OK) return rc;
+    }
 
     ctx.emit("classify", [a](hipStream_t s) {
         hipLaunchKernelGGL(instanceClassifyKernel<LATE>, dim3(a.numBlocks), dim3(kBlock), 0, s, a);

@@ -125,6 +125,47 @@ __global__ __launch_bounds__(1024) void spdTailKernel(SpdArgs a, uint32_t first)
     }
 }
 
+// Footprint-min table (trhip_texture_t::quad): entry (X, Y) of mip k, X in [0, w], Y in [0, h], is the min of
+// the texels {clamp(X-1), clamp(X)} x {clamp(Y-1), clamp(Y)} -- the footprint of a bilinear lookup whose
+// origin floor(uv*dim - 0.5) is (X-1, Y-1) and whose two weights per axis are non-zero (culling.hlsli:78
+// with the min-reduction sampler, CommonResources.cpp:276-287).  One thread per entry, all mips in one launch.
+struct QuadArgs
+{
+    const _Float16* base;
+    _Float16* out;
+    uint32_t width, height, mips, total;
+    uint32_t mipOffset[16];       // texels
+    uint32_t quadOffset[16];      // entries
+};
+
+__global__ __launch_bounds__(256) void hzbQuadBuildKernel(QuadArgs a)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.total) return;
+    uint32_t k = 0;
+    for (uint32_t m = 1; m < a.mips; ++m) k += i >= a.quadOffset[m] ? 1u : 0u;
+    const uint32_t mw = (a.width >> k) ? (a.width >> k) : 1u, mh = (a.height >> k) ? (a.height >> k) : 1u;
+    const uint32_t j = i - a.quadOffset[k];
+    const uint32_t X = j % (mw + 1u), Y = j / (mw + 1u);
+    const uint32_t xa = X ? X - 1u : 0u, xb = X < mw ? X : mw - 1u;
+    const uint32_t ya = Y ? Y - 1u : 0u, yb = Y < mh ? Y : mh - 1u;
+    const _Float16* t = a.base + a.mipOffset[k];
+    const float d00 = (float)t[ya * mw + xa], d01 = (float)t[ya * mw + xb];
+    const float d10 = (float)t[yb * mw + xa], d11 = (float)t[yb * mw + xb];
+    a.out[i] = (_Float16)cm::min_(cm::min_(cm::min_(d00, d01), d10), d11);     // min of fp16 values: exact
+}
+
+QuadArgs quadArgs(const trhip_texture_t* tex)
+{
+    QuadArgs a;
+    memset(&a, 0, sizeof a);
+    a.base = (const _Float16*)tex->ptr;
+    a.out = (_Float16*)tex->quad;
+    a.width = tex->width; a.height = tex->height; a.mips = tex->mips; a.total = tex->quadTotal;
+    for (uint32_t i = 0; i < tex->mips; ++i) { a.mipOffset[i] = (uint32_t)(tex->mipOffset[i] / 2); a.quadOffset[i] = tex->quadOffset[i]; }
+    return a;
+}
+
 int recordMinMaxDownsample(trhip::DispatchCtx& ctx)
 {
     // BasePassRenderers.cpp:515-536
@@ -148,6 +189,7 @@ int recordMinMaxDownsample(trhip::DispatchCtx& ctx)
     const uint32_t W = src->width, H = src->height, ow = dst->mipW(mip), oh = dst->mipH(mip);
     const bool mx = k->m_bDownsampleMax != 0;
     ctx.emit("main", [=](hipStream_t s) {
+        dst->quadValid = false;                                                     // the HZB is being rewritten
         dim3 grid((ow + 31) / 32, (oh + 7) / 8);
         if (mx) hipLaunchKernelGGL(minMaxDownsampleKernel<true>, grid, dim3(256), 0, s, depth, W, H, out, ow, oh);
         else hipLaunchKernelGGL(minMaxDownsampleKernel<false>, grid, dim3(256), 0, s, depth, W, H, out, ow, oh);
@@ -184,7 +226,8 @@ int recordSPD(trhip::DispatchCtx& ctx)
     const bool tiled = (tex->width % 64 == 0) && (tex->height % 64 == 0);
     if (tiled) {
         const uint32_t lastMip = tex->mips - 1 < 6 ? tex->mips - 1 : 6;
-        ctx.emit("tile", [a, lastMip, mx](hipStream_t s) {
+        ctx.emit("tile", [a, lastMip, mx, tex](hipStream_t s) {
+            tex->quadValid = false;
             dim3 grid(a.width / 64, a.height / 64);
             if (mx) hipLaunchKernelGGL(spdTileKernel<true>, grid, dim3(256), 0, s, a, lastMip);
             else hipLaunchKernelGGL(spdTileKernel<false>, grid, dim3(256), 0, s, a, lastMip);
@@ -195,13 +238,61 @@ int recordSPD(trhip::DispatchCtx& ctx)
                   "%s: HZB %ux%u: mip %u is larger than 64x64 texels (dimensions must be multiples of 64 or at most 64)",
                   ctx.shaderName, tex->width, tex->height, first);
     if (first + 1 < tex->mips) {
-        ctx.emit("tail", [a, first, mx](hipStream_t s) {
+        ctx.emit("tail", [a, first, mx, tex](hipStream_t s) {
+            tex->quadValid = false;
             if (mx) hipLaunchKernelGGL(spdTailKernel<true>, dim3(1), dim3(1024), 0, s, a, first);
             else hipLaunchKernelGGL(spdTailKernel<false>, dim3(1), dim3(1024), 0, s, a, first);
             return trhip::launchStatus("spdTailKernel"); });
     }
     return TRHIP_OK;
 }
+
+} // namespace
+
+namespace trhip
+{
+
+int hzbQuadEnsure(trhip_texture_t* tex)
+{
+    TRHIP_REQUIRE(tex && tex->ptr && tex->format == TRHIP_FORMAT_R16_FLOAT && tex->mips <= 16, "footprint-min table: needs a bound R16_FLOAT texture");
+    uint64_t total = 0;
+    for (uint32_t k = 0; k < tex->mips; ++k) {
+        tex->quadOffset[k] = (uint32_t)total;
+        total += (uint64_t)(tex->mipW(k) + 1) * (tex->mipH(k) + 1);
+    }
+    TRHIP_REQUIRE(total < (1ull << 31), "footprint-min table: HZB %ux%u too large", tex->width, tex->height);
+    tex->quadTotal = (uint32_t)total;
+    if (tex->quadBytes < total * 2) {
+        TRHIP_HIP(hipSetDevice(tex->dev->index));
+        if (tex->quad) { int rc = tex->dev->syncAll(); if (rc != TRHIP_OK) return rc; (void)hipFree(tex->quad); tex->quad = nullptr; tex->quadBytes = 0; }
+        TRHIP_HIP(hipMalloc(&tex->quad, (size_t)total * 2));
+        tex->quadBytes = total * 2;
+        tex->quadValid = false;
+    }
+    return TRHIP_OK;
+}
+
+int hzbQuadLaunchBuild(trhip_texture_t* tex, hipStream_t s)
+{
+    if (tex->quadValid) return TRHIP_OK;               // nothing wrote the HZB since the last build (submission order)
+    const QuadArgs a = quadArgs(tex);
+    hipLaunchKernelGGL(hzbQuadBuildKernel, dim3((a.total + 255u) / 256u), dim3(256), 0, s, a);
+    tex->quadValid = true;
+    return launchStatus("hzbQuadBuildKernel");
+}
+
+int hzbQuadEmitBuild(const DispatchCtx& ctx, trhip_texture_t* tex)
+{
+    int rc = hzbQuadEnsure(tex);
+    if (rc != TRHIP_OK) return rc;
+    ctx.emitSide("footprint_min", [tex](hipStream_t s) { return hzbQuadLaunchBuild(tex, s); }, { { tex->ptr, false }, { tex->quad, true } });
+    return TRHIP_OK;
+}
+
+} // namespace trhip
+
+namespace
+{
 
 trhip::ShaderRegistrar r0("minmaxdownsample_CS_Main", recordMinMaxDownsample, 0);
 trhip::ShaderRegistrar r1("ffx_spd_downsample_pass_CS FFX_SPD_OPTION_DOWNSAMPLE_FILTER=1", recordSPD, 1);

@@ -89,12 +89,12 @@ void DispatchCtx::emit(const char* kernelName, std::function<int(hipStream_t)> f
     cl->ops.push_back({ std::move(n), std::move(fn) });
 }
 
-void DispatchCtx::emitSide(const char* kernelName, std::function<int(hipStream_t)> fn, std::initializer_list<const void*> touched) const
+void DispatchCtx::emitSide(const char* kernelName, std::function<int(hipStream_t)> fn, std::initializer_list<Op::Access> touched) const
 {
     emit(kernelName, std::move(fn));
     if (!cl->dev->sideStream) return;                  // no side stream: plain in-order op
     cl->ops.back().lane = 1;
-    for (const void* p : touched) if (p) cl->ops.back().touched.push_back(p);
+    for (const Op::Access& t : touched) if (t.ptr) cl->ops.back().touched.push_back(t);
 }
 
 } // namespace trhip
@@ -233,8 +233,8 @@ int trhip_cmdlist_t::recordClearWords(void* ptr, uint64_t words, uint32_t value)
 
 // Every command holds the resources it uses before it is recorded: the one place that notes WHICH command
 // uses WHAT, for ordering against side-stream work on the same memory at execute time.
-void trhip_cmdlist_t::hold(trhip_buffer_t* b, size_t op) { if (b) { use(b->ptr, op == SIZE_MAX ? ops.size() : op); trhip_buffer_retain(b); heldBuffers.push_back(b); } }
-void trhip_cmdlist_t::hold(trhip_texture_t* t) { if (t) { use(t->ptr, ops.size()); trhip_texture_retain(t); heldTextures.push_back(t); } }
+void trhip_cmdlist_t::hold(trhip_buffer_t* b, bool write, size_t op) { if (b) { use(b->ptr, op == SIZE_MAX ? ops.size() : op, write); trhip_buffer_retain(b); heldBuffers.push_back(b); } }
+void trhip_cmdlist_t::hold(trhip_texture_t* t, bool write) { if (t) { use(t->ptr, ops.size(), write); trhip_texture_retain(t); heldTextures.push_back(t); } }
 
 // ------------------------------------------------------------------------------------------------
 extern "C" {
@@ -472,6 +472,7 @@ void trhip_texture_release(trhip_texture t)
     if (!t) return;
     if (t->rc.fetch_sub(1) == 1) {
         if (t->owns && t->ptr) { (void)hipSetDevice(t->dev->index); (void)hipFree(t->ptr); }
+        if (t->quad) { (void)hipSetDevice(t->dev->index); (void)t->dev->syncAll(); (void)hipFree(t->quad); }
         if (t->heap) trhip_heap_release(t->heap);
         delete t;
     }
@@ -520,7 +521,9 @@ int trhip_texture_upload(trhip_texture t, uint32_t mip, const void* src, uint64_
     if (!t->ptr) return fail(TRHIP_ERR_STATE, "texture_upload(%s): no memory bound", t->name.c_str());
     uint64_t need = (uint64_t)t->mipW(mip) * t->mipH(mip) * t->texelBytes;
     if (bytes != need) return fail(TRHIP_ERR_INVALID, "texture_upload(%s): mip %u is %llu bytes, got %llu", t->name.c_str(), mip, (unsigned long long)need, (unsigned long long)bytes);
-    return syncCopy(t->dev, t->mipPtr(mip), src, bytes, hipMemcpyHostToDevice);
+    int rc = syncCopy(t->dev, t->mipPtr(mip), src, bytes, hipMemcpyHostToDevice);
+    t->quadValid = false;                      // everything submitted has completed: later submissions see the new contents
+    return rc;
 }
 
 int trhip_texture_download(trhip_texture t, uint32_t mip, void* dst, uint64_t bytes)
@@ -591,7 +594,7 @@ int trhip_cmd_write_buffer(trhip_cmdlist cl, trhip_buffer buf, uint64_t off, con
     if (!buf->ptr) return fail(TRHIP_ERR_STATE, "write_buffer(%s): no memory bound", buf->name.c_str());
     auto staged = std::make_shared<std::vector<uint8_t>>((const uint8_t*)src, (const uint8_t*)src + bytes);
     void* dst = (char*)buf->ptr + off;
-    cl->hold(buf);
+    cl->hold(buf, true);
     cl->ops.push_back({ "", [staged, dst](hipStream_t s) {
         TRHIP_HIP(hipMemcpyAsync(dst, staged->data(), staged->size(), hipMemcpyHostToDevice, s));
         return (int)TRHIP_OK; } });
@@ -606,7 +609,7 @@ int trhip_cmd_clear_buffer_u32(trhip_cmdlist cl, trhip_buffer buf, uint32_t valu
     if (!buf->ptr) return fail(TRHIP_ERR_STATE, "clear_buffer(%s): no memory bound", buf->name.c_str());
     if (buf->byteSize % 4) return fail(TRHIP_ERR_INVALID, "clear_buffer(%s): size not a multiple of 4", buf->name.c_str());
     const bool merges = cl->openClearBatch && cl->openClearOp == cl->ops.size() - 1 && cl->openClearBatch->count < trhip_cmdlist_t::ClearBatch::kMax;
-    cl->hold(buf, merges ? cl->openClearOp : cl->ops.size());
+    cl->hold(buf, true, merges ? cl->openClearOp : cl->ops.size());
     return cl->recordClearWords(buf->ptr, buf->byteSize / 4, value);
 }
 
@@ -616,19 +619,19 @@ int trhip_cmd_clear_texture_f32(trhip_cmdlist cl, trhip_texture tex, float value
     if (!tex) return fail(TRHIP_ERR_INVALID, "clear_texture: null texture");
     if (!tex->ptr) return fail(TRHIP_ERR_STATE, "clear_texture(%s): no memory bound", tex->name.c_str());
     void* p = tex->ptr;
-    cl->hold(tex);
+    cl->hold(tex, true);
     if (tex->format == TRHIP_FORMAT_R32_FLOAT) {
         uint32_t bits;
         memcpy(&bits, &value, 4);
         size_t n = (size_t)(tex->totalBytes / 4);
-        cl->ops.push_back({ "", [p, n, bits](hipStream_t s) { TRHIP_HIP(hipMemsetD32Async((hipDeviceptr_t)p, (int)bits, n, s)); return (int)TRHIP_OK; } });
+        cl->ops.push_back({ "", [p, n, bits, tex](hipStream_t s) { tex->quadValid = false; TRHIP_HIP(hipMemsetD32Async((hipDeviceptr_t)p, (int)bits, n, s)); return (int)TRHIP_OK; } });
         cl->ops.back().kind = "clear_texture";
     } else {
         _Float16 h = (_Float16)value; // round-to-nearest-even
         uint16_t bits;
         memcpy(&bits, &h, 2);
         size_t n = (size_t)(tex->totalBytes / 2);
-        cl->ops.push_back({ "", [p, n, bits](hipStream_t s) { TRHIP_HIP(hipMemsetD16Async((hipDeviceptr_t)p, bits, n, s)); return (int)TRHIP_OK; } });
+        cl->ops.push_back({ "", [p, n, bits, tex](hipStream_t s) { tex->quadValid = false; TRHIP_HIP(hipMemsetD16Async((hipDeviceptr_t)p, bits, n, s)); return (int)TRHIP_OK; } });
         cl->ops.back().kind = "clear_texture";
     }
     return TRHIP_OK;
@@ -642,7 +645,7 @@ int trhip_cmd_copy_buffer(trhip_cmdlist cl, trhip_buffer dst, uint64_t dstOff, t
     if (dstOff + bytes > dst->byteSize || srcOff + bytes > src->byteSize) return fail(TRHIP_ERR_INVALID, "copy_buffer(%s <- %s): range exceeds a buffer", dst->name.c_str(), src->name.c_str());
     void* d = (char*)dst->ptr + dstOff;
     const void* sp = (const char*)src->ptr + srcOff;
-    cl->hold(dst); cl->hold(src);
+    cl->hold(dst, true); cl->hold(src, false);
     cl->ops.push_back({ "", [d, sp, bytes](hipStream_t s) { TRHIP_HIP(hipMemcpyAsync(d, sp, (size_t)bytes, hipMemcpyDeviceToDevice, s)); return (int)TRHIP_OK; } });
     cl->ops.back().kind = "copy_buffer";
     return TRHIP_OK;
@@ -667,8 +670,8 @@ int trhip_cmd_copy_texture(trhip_cmdlist cl, trhip_texture dst, trhip_texture sr
     void* d = dst->ptr;
     const void* sp = src->ptr;
     const uint64_t bytes = src->totalBytes;
-    cl->hold(dst); cl->hold(src);
-    cl->ops.push_back({ "", [d, sp, bytes](hipStream_t s) { TRHIP_HIP(hipMemcpyAsync(d, sp, (size_t)bytes, hipMemcpyDeviceToDevice, s)); return (int)TRHIP_OK; } });
+    cl->hold(dst, true); cl->hold(src, false);
+    cl->ops.push_back({ "", [d, sp, bytes, dst](hipStream_t s) { dst->quadValid = false; TRHIP_HIP(hipMemcpyAsync(d, sp, (size_t)bytes, hipMemcpyDeviceToDevice, s)); return (int)TRHIP_OK; } });
     cl->ops.back().kind = "copy_texture";
     return TRHIP_OK;
 }
@@ -684,7 +687,7 @@ static int recordDispatch(trhip_cmdlist cl, const char* name, const trhip_bindin
     if (indirect) {
         if (!args || !args->ptr) return fail(TRHIP_ERR_INVALID, "dispatch_indirect(%s): no argument buffer", name);
         if (argsOff % 4 || argsOff + 12 > args->byteSize) return fail(TRHIP_ERR_INVALID, "dispatch_indirect(%s): bad argument offset %u", name, argsOff);
-        cl->hold(args);
+        cl->hold(args, false);
     } else if (gx == 0 || gy == 0 || gz == 0) {
         return fail(TRHIP_ERR_INVALID, "dispatch(%s): zero group count (Graphic.cpp:944)", name);
     }
@@ -695,14 +698,14 @@ static int recordDispatch(trhip_cmdlist cl, const char* name, const trhip_bindin
             if (!r) return fail(TRHIP_ERR_INVALID, "dispatch(%s): binding %u has no buffer", name, i);
             if (b[i].type != TRHIP_BIND_CONSTANT_BUFFER && !r->ptr) return fail(TRHIP_ERR_STATE, "dispatch(%s): buffer '%s' has no memory bound", name, r->name.c_str());
             if (b[i].type == TRHIP_BIND_STRUCTURED_UAV && !r->canHaveUAVs) return fail(TRHIP_ERR_INVALID, "dispatch(%s): buffer '%s' bound as UAV without canHaveUAVs", name, r->name.c_str());
-            cl->hold(r);
+            cl->hold(r, b[i].type == TRHIP_BIND_STRUCTURED_UAV);
             break; }
         case TRHIP_BIND_TEXTURE_SRV: case TRHIP_BIND_TEXTURE_UAV: {
             trhip_texture_t* t = (trhip_texture_t*)b[i].resource;
             if (!t) return fail(TRHIP_ERR_INVALID, "dispatch(%s): binding %u has no texture", name, i);
             if (!t->ptr) return fail(TRHIP_ERR_STATE, "dispatch(%s): texture '%s' has no memory bound", name, t->name.c_str());
             if (b[i].type == TRHIP_BIND_TEXTURE_UAV && b[i].baseMip >= t->mips) return fail(TRHIP_ERR_INVALID, "dispatch(%s): UAV mip %u out of range", name, b[i].baseMip);
-            cl->hold(t);
+            cl->hold(t, b[i].type == TRHIP_BIND_TEXTURE_UAV);
             break; }
         case TRHIP_BIND_PUSH_CONSTANTS: case TRHIP_BIND_SAMPLER: break;
         default: return fail(TRHIP_ERR_INVALID, "dispatch(%s): binding %u has unknown type %u", name, i, b[i].type);
@@ -763,7 +766,7 @@ int trhip_queue_execute(trhip_device dev, const trhip_cmdlist* lists, uint32_t n
     TRHIP_HIP(hipSetDevice(dev->index));
     std::lock_guard<std::mutex> lock(dev->mutex);
     bool inRun = false;
-    std::vector<const void*> runTouched;
+    std::vector<Op::Access> runTouched;
     auto endRun = [&]() -> int {                       // the side stream's current run is complete: publish its event
         if (!inRun) return TRHIP_OK;
         inRun = false;
@@ -774,16 +777,21 @@ int trhip_queue_execute(trhip_device dev, const trhip_cmdlist* lists, uint32_t n
             dev->mainWaitedUpTo = id - trhip_device_t::kSideRuns;
         }
         TRHIP_HIP(hipEventRecord(dev->runDone[slot], dev->sideStream));
-        for (const void* p : runTouched) dev->sideOwner[p] = id;
+        for (const Op::Access& t : runTouched) (t.write ? dev->sideWriter : dev->sideReader)[t.ptr] = id;
         runTouched.clear();
         return TRHIP_OK;
     };
-    auto waitForOwner = [&](const void* ptr) -> int {   // a main-stream command uses `ptr`
-        if (dev->sideOwner.empty()) return TRHIP_OK;
-        auto it = dev->sideOwner.find(ptr);
-        if (it == dev->sideOwner.end() || it->second <= dev->mainWaitedUpTo) return TRHIP_OK;
-        TRHIP_HIP(hipStreamWaitEvent(dev->stream, dev->runDone[it->second % trhip_device_t::kSideRuns], 0));
-        dev->mainWaitedUpTo = it->second;              // the side stream is in order: earlier runs are covered too
+    auto waitForOwner = [&](const void* ptr, bool write) -> int {   // a main-stream command reads / writes `ptr`
+        uint64_t need = 0;                             // read after side write; write after side write or read
+        auto w = dev->sideWriter.find(ptr);
+        if (w != dev->sideWriter.end()) need = w->second;
+        if (write) {
+            auto r = dev->sideReader.find(ptr);
+            if (r != dev->sideReader.end() && r->second > need) need = r->second;
+        }
+        if (need <= dev->mainWaitedUpTo) return TRHIP_OK;
+        TRHIP_HIP(hipStreamWaitEvent(dev->stream, dev->runDone[need % trhip_device_t::kSideRuns], 0));
+        dev->mainWaitedUpTo = need;                    // the side stream is in order: earlier runs are covered too
         return TRHIP_OK;
     };
     for (uint32_t i = 0; i < n; ++i) {
@@ -809,7 +817,7 @@ int trhip_queue_execute(trhip_device dev, const trhip_cmdlist* lists, uint32_t n
                 int rc = endRun();
                 if (rc != TRHIP_OK) return rc;
                 for (; mark < cl->useMarks.size() && cl->useMarks[mark].op <= oi; ++mark) {
-                    rc = waitForOwner(cl->useMarks[mark].ptr);
+                    rc = waitForOwner(cl->useMarks[mark].ptr, cl->useMarks[mark].write);
                     if (rc != TRHIP_OK) return rc;
                 }
             }

@@ -60,7 +60,8 @@ struct trhip_device_t
     hipEvent_t runDone[kSideRuns] = {};
     uint64_t sideRunCounter = 0;               // id of the last finished run (ids start at 1)
     uint64_t mainWaitedUpTo = 0;               // the main stream is ordered after all runs <= this id
-    std::unordered_map<const void*, uint64_t> sideOwner;   // allocation -> last run that touched it
+    std::unordered_map<const void*, uint64_t> sideWriter;  // allocation -> last run that wrote it
+    std::unordered_map<const void*, uint64_t> sideReader;  // allocation -> last run that read it
     int syncAll();                             // host wait for both streams
 
     std::mutex mutex;
@@ -113,6 +114,16 @@ struct trhip_texture_t
     void* ptr = nullptr;
     bool owns = false;
     trhip_heap_t* heap = nullptr;
+    // Back-end private companion of an R16F min-HZB: the FOOTPRINT-MIN TABLE (k_hzb.hip).  For every mip and
+    // every possible bilinear footprint origin (x0,y0) in [-1,w-1]x[-1,h-1] it holds the min of the 2x2
+    // edge-clamped footprint, so the meshlet cull kernel resolves SampleLevel(min-reduction) with ONE 2-byte
+    // load.  quadValid is flipped on the host in SUBMISSION order (inside the ops' launch lambdas): false by
+    // everything that writes the texture, true by the table build.
+    void* quad = nullptr;
+    uint64_t quadBytes = 0;
+    uint32_t quadOffset[16] = {};              // first entry of mip k; mip k has (w_k + 1) * (h_k + 1) entries
+    uint32_t quadTotal = 0;
+    std::atomic<bool> quadValid{false};
     std::atomic<int> rc{1};
 
     uint32_t mipW(uint32_t k) const { return (width >> k) ? (width >> k) : 1u; }
@@ -136,7 +147,8 @@ struct Op
     std::function<int(hipStream_t)> fn;
     const char* kind = "dispatch";          // what the op is, for the host-side submission profile (TRHIP_HOST_PROFILE=1)
     uint8_t lane = 0;                       // 0 main stream, 1 side stream (see DispatchCtx::emitSide)
-    std::vector<const void*> touched;       // side ops: allocations read or written (base pointers)
+    struct Access { const void* ptr; bool write; };
+    std::vector<Access> touched;            // side ops: allocations read / written (base pointers)
 };
 
 } // namespace trhip
@@ -162,16 +174,17 @@ struct trhip_cmdlist_t
 
     // Which allocations each command uses (recorded by hold()): checked against the side stream's runs
     // when the list is executed.
-    struct UseMark { size_t op; const void* ptr; };
+    struct UseMark { size_t op; const void* ptr; bool write; };
     std::vector<UseMark> useMarks;
-    void use(const void* ptr, size_t op) { if (ptr) useMarks.push_back({ op, ptr }); }
+    void use(const void* ptr, size_t op, bool write) { if (ptr) useMarks.push_back({ op, ptr, write }); }
 
     void* scratchAlloc(size_t bytes);       // device memory valid until the list is re-opened/released
     void* scratchAllocSide(size_t bytes);   // same, from an arena only side-stream ops use (they are in order among themselves)
     std::vector<ScratchBlock> sideScratch;
     void resetRecording();
-    void hold(trhip_buffer_t* b, size_t op = SIZE_MAX);     // op: index of the command that uses it (default: the next one)
-    void hold(trhip_texture_t* t);
+    // write: the command writes the resource; op: index of the command that uses it (default: the next one)
+    void hold(trhip_buffer_t* b, bool write, size_t op = SIZE_MAX);
+    void hold(trhip_texture_t* t, bool write);
 };
 
 namespace trhip
@@ -199,8 +212,14 @@ struct DispatchCtx
     void emit(const char* kernelName, std::function<int(hipStream_t)> fn) const;
     // Same, on the device's side stream, ordered after everything recorded before it.  `touched`: every
     // device allocation the op reads or writes that a later command could also use (base pointers).
-    void emitSide(const char* kernelName, std::function<int(hipStream_t)> fn, std::initializer_list<const void*> touched) const;
+    void emitSide(const char* kernelName, std::function<int(hipStream_t)> fn, std::initializer_list<Op::Access> touched) const;
 };
+
+// Footprint-min table of an HZB (trhip_texture_t::quad), k_hzb.hip.  ensure: allocate + lay out (record time);
+// emit: a command that rebuilds it (side stream when there is one); launch: rebuild right now on `s`.
+int hzbQuadEnsure(trhip_texture_t* tex);
+int hzbQuadEmitBuild(const DispatchCtx& ctx, trhip_texture_t* tex);
+int hzbQuadLaunchBuild(trhip_texture_t* tex, hipStream_t s);
 
 using RecordFn = int (*)(DispatchCtx&);
 void registerShader(const char* name, RecordFn fn, int variant);
