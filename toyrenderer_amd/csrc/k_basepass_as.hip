@@ -755,7 +755,7 @@ int recordASMain(trhip::DispatchCtx& ctx)
     const bool table = useTable;
     if (quadOwner) ctx.cl->use(quadOwner->quad, ctx.cl->ops.size(), false);     // the kernel reads the table: ordered after a side-stream rebuild
     ctx.emit("cull", [a, grid, flags, quadOwner, table](hipStream_t s) {
-        if (quadOwner && !quadOwner->quadValid) {          // the HZB was written since its table was built (upload, clear, copy)
+        if (quadOwner) {                                   // no-op unless the HZB was written since its table was built
             int brc = trhip::hzbQuadLaunchBuild(quadOwner, s);
             if (brc != TRHIP_OK) return brc;
         }

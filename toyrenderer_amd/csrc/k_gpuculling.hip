@@ -28,6 +28,32 @@ constexpr uint32_t kWordSubmit = 1u << 30;
 constexpr uint32_t kWordLate = 1u << 31;
 constexpr uint32_t kGroupMask = (1u << 27) - 1u;
 
+// Instance cull cache (trhip_buffer_t::cullCache): SoA over instance ids, built by instanceCacheKernel whenever
+// the instance or mesh buffer has been written since (version counters).  Same arithmetic as the direct path,
+// so the cached values are bit-identical to what classify() would compute from the AoS records.
+struct InstanceCullCache
+{
+    const float4* sphere;           // world-space bounding sphere: TransformBoundingSphereToWorld (gpuculling.hlsl:116)
+    const float* maxScale;          // toyrenderer_common.hlsli:134-140
+    const uint32_t* numLODs;
+    const uint32_t* numMeshlets;    // [id][kMaxNumMeshLODs]
+    const float* error;             // [id][kMaxNumMeshLODs]
+};
+
+constexpr uint64_t kCacheBytesPerInstance = 16 + 4 + 4 + 4 * kMaxNumMeshLODs + 4 * kMaxNumMeshLODs;
+
+InstanceCullCache cacheLayout(void* base, uint64_t n)
+{
+    char* p = (char*)base;
+    InstanceCullCache c;
+    c.sphere = (const float4*)p;            p += 16 * n;
+    c.maxScale = (const float*)p;           p += 4 * n;
+    c.numLODs = (const uint32_t*)p;         p += 4 * n;
+    c.numMeshlets = (const uint32_t*)p;     p += 4ull * kMaxNumMeshLODs * n;
+    c.error = (const float*)p;
+    return c;
+}
+
 struct InstanceCullArgs
 {
     GPUCullingPassConstants k;
@@ -40,6 +66,8 @@ struct InstanceCullArgs
     uint32_t* lateCount;
     uint32_t* lateIds;
     const uint32_t* indirectArgs;   // late: {ceil(count/64),1,1} (Q1)
+    InstanceCullCache cache;
+    uint32_t numInstances;          // entries of the instance buffer (= of the cache)
     const uint32_t* shardLate;      // late, multi-GPU only: {late entries of the lower ranks, of all ranks} (trhip.h)
     uint32_t directThreads;         // early: gx * 32
     uint32_t maxGroups;             // capacity of `records` (65535 in the reference, Q2)
@@ -61,6 +89,43 @@ struct InstanceCullArgs
     uint32_t* perm;
     uint32_t permCapacity;
 };
+
+__global__ __launch_bounds__(256) void instanceCacheKernel(const BasePassInstanceConstants* instances, uint32_t n,
+                                                           const MeshData* meshData, uint32_t numMeshes, InstanceCullCache c)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const BasePassInstanceConstants& inst = instances[i];
+    const float4 w0 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[0]);
+    const float4 w1 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[1]);
+    const float4 w2 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[2]);
+    const float4 w3 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[3]);
+    const cm::M43 W = { { w0.x, w0.y, w0.z }, { w1.x, w1.y, w1.z }, { w2.x, w2.y, w2.z }, { w3.x, w3.y, w3.z } };
+    const uint32_t meshIdx = inst.m_MeshDataIdx;
+    float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t numLODs = 0;
+    uint32_t nm[kMaxNumMeshLODs];
+    float err[kMaxNumMeshLODs];
+#pragma unroll
+    for (uint32_t l = 0; l < kMaxNumMeshLODs; ++l) { nm[l] = 0; err[l] = 0.f; }
+    if (meshIdx < numMeshes) {                                                       // never read outside the mesh table
+        const MeshData& mesh = meshData[meshIdx];
+        sph = *reinterpret_cast<const float4*>(&mesh.m_BoundingSphere);
+        numLODs = mesh.m_NumLODs;
+#pragma unroll
+        for (uint32_t l = 0; l < kMaxNumMeshLODs; ++l) { nm[l] = mesh.m_MeshLODDatas[l].m_NumMeshlets; err[l] = mesh.m_MeshLODDatas[l].m_Error; }
+    }
+    const float ms = cm::maxScale(W.r0, W.r1, W.r2);
+    const cm::F3 wc = cm::mulPoint({ sph.x, sph.y, sph.z }, W);                      // :116 TransformBoundingSphereToWorld
+    const_cast<float4*>(c.sphere)[i] = make_float4(wc.x, wc.y, wc.z, sph.w * ms);
+    const_cast<float*>(c.maxScale)[i] = ms;
+    const_cast<uint32_t*>(c.numLODs)[i] = numLODs;
+#pragma unroll
+    for (uint32_t l = 0; l < kMaxNumMeshLODs; ++l) {
+        const_cast<uint32_t*>(c.numMeshlets)[(uint64_t)i * kMaxNumMeshLODs + l] = nm[l];
+        const_cast<float*>(c.error)[(uint64_t)i * kMaxNumMeshLODs + l] = err[l];
+    }
+}
 
 constexpr uint32_t kTilesPerAxis = 32;
 constexpr uint32_t kNumTiles = kTilesPerAxis * kTilesPerAxis;
@@ -117,18 +182,12 @@ __device__ __forceinline__ uint32_t classify(const InstanceCullArgs& a, uint32_t
     const bool doFrustum = (k.m_CullingFlags & kCullingFlagFrustumCullingEnable) != 0;
     const bool doOcclusion = (k.m_CullingFlags & kCullingFlagOcclusionCullingEnable) != 0;
 
-    const BasePassInstanceConstants& inst = a.instances[id];                       // :114
-    const float4 w0 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[0]);
-    const float4 w1 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[1]);
-    const float4 w2 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[2]);
-    const float4 w3 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[3]);
-    const cm::M43 W = { { w0.x, w0.y, w0.z }, { w1.x, w1.y, w1.z }, { w2.x, w2.y, w2.z }, { w3.x, w3.y, w3.z } };
-    const MeshData& mesh = a.meshData[inst.m_MeshDataIdx];
-    const float4 sph = *reinterpret_cast<const float4*>(&mesh.m_BoundingSphere);
-
-    const float ms = cm::maxScale(W.r0, W.r1, W.r2);
-    const cm::F3 wc = cm::mulPoint({ sph.x, sph.y, sph.z }, W);                    // :116 TransformBoundingSphereToWorld
-    const float r = sph.w * ms;
+    // :114-116 through the instance cull cache (same values as from a.instances[id] / a.meshData[...])
+    const uint32_t cid = id < a.numInstances ? id : 0u;                             // never read outside the cache
+    const float4 ws = a.cache.sphere[cid];
+    const float ms = a.cache.maxScale[cid];
+    const cm::F3 wc = { ws.x, ws.y, ws.z };
+    const float r = ws.w;
     cm::F3 cv = cm::toView(wc, cm::loadM43(k.m_WorldToView));                      // :118-119
 
     if (!LATE && doFrustum &&                                                      // :124-134
@@ -142,7 +201,9 @@ __device__ __forceinline__ uint32_t classify(const InstanceCullArgs& a, uint32_t
     }
 
     // SubmitInstance :35-62
-    const uint32_t numLODs = mesh.m_NumLODs;
+    const uint32_t numLODs = a.cache.numLODs[cid];
+    const uint32_t* lodMeshlets = a.cache.numMeshlets + (uint64_t)cid * kMaxNumMeshLODs;
+    const float* lodError = a.cache.error + (uint64_t)cid * kMaxNumMeshLODs;
     uint32_t lod = 0;
     if (k.m_ForcedMeshLOD != kInvalidMeshLOD) {
         const uint32_t last = numLODs - 1u;
@@ -152,10 +213,10 @@ __device__ __forceinline__ uint32_t classify(const InstanceCullArgs& a, uint32_t
         const float threshold = distance * k.m_MeshLODTarget / ms;
         const uint32_t n = numLODs < kMaxNumMeshLODs ? numLODs : kMaxNumMeshLODs;
         for (uint32_t i = 1; i < n; ++i)
-            if (mesh.m_MeshLODDatas[i].m_Error < threshold) lod = i;
+            if (lodError[i] < threshold) lod = i;
     }
-    lod = lod < kMaxNumMeshLODs ? lod : kMaxNumMeshLODs - 1u;                       // never index past the struct
-    const uint32_t numMeshlets = mesh.m_MeshLODDatas[lod].m_NumMeshlets;
+    lod = lod < kMaxNumMeshLODs ? lod : kMaxNumMeshLODs - 1u;                       // never index past the table
+    const uint32_t numMeshlets = lodMeshlets[lod];
     const uint32_t groups = (numMeshlets + kNumThreadsPerWave - 1u) / kNumThreadsPerWave; // DivideAndRoundUp
     *tileOut = screenTile(cv, k.m_P00, k.m_P11);
     return kWordSubmit | (lod << 27) | (groups & kGroupMask);
@@ -417,6 +478,32 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
 
     const uint32_t nMax = k->m_NbInstances;
     if (nMax == 0) return TRHIP_OK;
+
+    // instance cull cache: (re)built, in submission order, when the instance or the mesh buffer has been written
+    const uint64_t numInst = instances->byteSize / sizeof(BasePassInstanceConstants);
+    const uint64_t numMeshes = meshData->byteSize / sizeof(MeshData);
+    TRHIP_REQUIRE(numInst >= 1 && numInst <= 0xFFFFFFFFull && numMeshes <= 0xFFFFFFFFull, "%s: instance / mesh buffer sizes out of range", ctx.shaderName);
+    if (instances->cullCacheBytes < numInst * kCacheBytesPerInstance) {
+        TRHIP_HIP(hipSetDevice(ctx.cl->dev->index));
+        if (instances->cullCache) { rc = ctx.cl->dev->syncAll(); if (rc != TRHIP_OK) return rc; (void)hipFree(instances->cullCache); instances->cullCache = nullptr; instances->cullCacheBytes = 0; }
+        TRHIP_HIP(hipMalloc(&instances->cullCache, (size_t)(numInst * kCacheBytesPerInstance)));
+        instances->cullCacheBytes = numInst * kCacheBytesPerInstance;
+        instances->cullCacheInstVersion = 0;
+    }
+    a.cache = cacheLayout(instances->cullCache, numInst);
+    a.numInstances = (uint32_t)numInst;
+    {
+        const InstanceCullCache c = a.cache;
+        const BasePassInstanceConstants* ip = a.instances;
+        const MeshData* mp = a.meshData;
+        const uint32_t ni = (uint32_t)numInst, nmesh = (uint32_t)numMeshes;
+        ctx.emit("instance_cache", [instances, meshData, c, ip, mp, ni, nmesh](hipStream_t s) {
+            const uint64_t vi = instances->version, vm = meshData->version;      // every earlier write is counted (submission order)
+            if (instances->cullCacheInstVersion == vi && instances->cullCacheMeshVersion == vm && instances->cullCacheMesh == mp) return (int)TRHIP_OK;
+            hipLaunchKernelGGL(instanceCacheKernel, dim3((ni + 255u) / 256u), dim3(256), 0, s, ip, ni, mp, nmesh, c);
+            instances->cullCacheInstVersion = vi; instances->cullCacheMeshVersion = vm; instances->cullCacheMesh = mp;
+            return trhip::launchStatus("instanceCacheKernel"); });
+    }
     a.numBlocks = (nMax + kBlock - 1) / kBlock;
     a.word = (uint32_t*)ctx.scratch((size_t)nMax * 4);
     a.localOff = (uint32_t*)ctx.scratch((size_t)nMax * 4);

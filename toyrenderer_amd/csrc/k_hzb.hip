@@ -189,7 +189,6 @@ int recordMinMaxDownsample(trhip::DispatchCtx& ctx)
     const uint32_t W = src->width, H = src->height, ow = dst->mipW(mip), oh = dst->mipH(mip);
     const bool mx = k->m_bDownsampleMax != 0;
     ctx.emit("main", [=](hipStream_t s) {
-        dst->quadValid = false;                                                     // the HZB is being rewritten
         dim3 grid((ow + 31) / 32, (oh + 7) / 8);
         if (mx) hipLaunchKernelGGL(minMaxDownsampleKernel<true>, grid, dim3(256), 0, s, depth, W, H, out, ow, oh);
         else hipLaunchKernelGGL(minMaxDownsampleKernel<false>, grid, dim3(256), 0, s, depth, W, H, out, ow, oh);
@@ -226,8 +225,7 @@ int recordSPD(trhip::DispatchCtx& ctx)
     const bool tiled = (tex->width % 64 == 0) && (tex->height % 64 == 0);
     if (tiled) {
         const uint32_t lastMip = tex->mips - 1 < 6 ? tex->mips - 1 : 6;
-        ctx.emit("tile", [a, lastMip, mx, tex](hipStream_t s) {
-            tex->quadValid = false;
+        ctx.emit("tile", [a, lastMip, mx](hipStream_t s) {
             dim3 grid(a.width / 64, a.height / 64);
             if (mx) hipLaunchKernelGGL(spdTileKernel<true>, grid, dim3(256), 0, s, a, lastMip);
             else hipLaunchKernelGGL(spdTileKernel<false>, grid, dim3(256), 0, s, a, lastMip);
@@ -238,8 +236,7 @@ int recordSPD(trhip::DispatchCtx& ctx)
                   "%s: HZB %ux%u: mip %u is larger than 64x64 texels (dimensions must be multiples of 64 or at most 64)",
                   ctx.shaderName, tex->width, tex->height, first);
     if (first + 1 < tex->mips) {
-        ctx.emit("tail", [a, first, mx, tex](hipStream_t s) {
-            tex->quadValid = false;
+        ctx.emit("tail", [a, first, mx](hipStream_t s) {
             if (mx) hipLaunchKernelGGL(spdTailKernel<true>, dim3(1), dim3(1024), 0, s, a, first);
             else hipLaunchKernelGGL(spdTailKernel<false>, dim3(1), dim3(1024), 0, s, a, first);
             return trhip::launchStatus("spdTailKernel"); });
@@ -267,17 +264,18 @@ int hzbQuadEnsure(trhip_texture_t* tex)
         if (tex->quad) { int rc = tex->dev->syncAll(); if (rc != TRHIP_OK) return rc; (void)hipFree(tex->quad); tex->quad = nullptr; tex->quadBytes = 0; }
         TRHIP_HIP(hipMalloc(&tex->quad, (size_t)total * 2));
         tex->quadBytes = total * 2;
-        tex->quadValid = false;
+        tex->quadBuiltVersion = 0;
     }
     return TRHIP_OK;
 }
 
 int hzbQuadLaunchBuild(trhip_texture_t* tex, hipStream_t s)
 {
-    if (tex->quadValid) return TRHIP_OK;               // nothing wrote the HZB since the last build (submission order)
+    const uint64_t v = tex->version;                   // called while commands are submitted: every earlier write is counted
+    if (tex->quadBuiltVersion == v) return TRHIP_OK;   // nothing wrote the HZB since the last build
     const QuadArgs a = quadArgs(tex);
     hipLaunchKernelGGL(hzbQuadBuildKernel, dim3((a.total + 255u) / 256u), dim3(256), 0, s, a);
-    tex->quadValid = true;
+    tex->quadBuiltVersion = v;
     return launchStatus("hzbQuadBuildKernel");
 }
 

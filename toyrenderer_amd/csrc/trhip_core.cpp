@@ -233,8 +233,8 @@ int trhip_cmdlist_t::recordClearWords(void* ptr, uint64_t words, uint32_t value)
 
 // Every command holds the resources it uses before it is recorded: the one place that notes WHICH command
 // uses WHAT, for ordering against side-stream work on the same memory at execute time.
-void trhip_cmdlist_t::hold(trhip_buffer_t* b, bool write, size_t op) { if (b) { use(b->ptr, op == SIZE_MAX ? ops.size() : op, write); trhip_buffer_retain(b); heldBuffers.push_back(b); } }
-void trhip_cmdlist_t::hold(trhip_texture_t* t, bool write) { if (t) { use(t->ptr, ops.size(), write); trhip_texture_retain(t); heldTextures.push_back(t); } }
+void trhip_cmdlist_t::hold(trhip_buffer_t* b, bool write, size_t op) { if (b) { use(b->ptr, op == SIZE_MAX ? ops.size() : op, write, &b->version); trhip_buffer_retain(b); heldBuffers.push_back(b); } }
+void trhip_cmdlist_t::hold(trhip_texture_t* t, bool write) { if (t) { use(t->ptr, ops.size(), write, &t->version); trhip_texture_retain(t); heldTextures.push_back(t); } }
 
 // ------------------------------------------------------------------------------------------------
 extern "C" {
@@ -409,6 +409,7 @@ void trhip_buffer_release(trhip_buffer b)
     if (b->rc.fetch_sub(1) == 1) {
         if (b->owns && b->ptr) { (void)hipSetDevice(b->dev->index); (void)hipFree(b->ptr); }
         if (b->sidecar) { (void)hipSetDevice(b->dev->index); (void)hipFree(b->sidecar); }
+        if (b->cullCache) { (void)hipSetDevice(b->dev->index); (void)b->dev->syncAll(); (void)hipFree(b->cullCache); }
         if (b->heap) trhip_heap_release(b->heap);
         delete b;
     }
@@ -504,7 +505,9 @@ int trhip_buffer_upload(trhip_buffer b, uint64_t off, const void* src, uint64_t 
     if (!b || !src) return fail(TRHIP_ERR_INVALID, "buffer_upload: null argument");
     if (!b->ptr) return fail(TRHIP_ERR_STATE, "buffer_upload(%s): no memory bound", b->name.c_str());
     if (off + bytes > b->byteSize) return fail(TRHIP_ERR_INVALID, "buffer_upload(%s): range exceeds the buffer", b->name.c_str());
-    return syncCopy(b->dev, (char*)b->ptr + off, src, bytes, hipMemcpyHostToDevice);
+    int rc = syncCopy(b->dev, (char*)b->ptr + off, src, bytes, hipMemcpyHostToDevice);
+    b->version.fetch_add(1);
+    return rc;
 }
 
 int trhip_buffer_download(trhip_buffer b, uint64_t off, void* dst, uint64_t bytes)
@@ -522,7 +525,7 @@ int trhip_texture_upload(trhip_texture t, uint32_t mip, const void* src, uint64_
     uint64_t need = (uint64_t)t->mipW(mip) * t->mipH(mip) * t->texelBytes;
     if (bytes != need) return fail(TRHIP_ERR_INVALID, "texture_upload(%s): mip %u is %llu bytes, got %llu", t->name.c_str(), mip, (unsigned long long)need, (unsigned long long)bytes);
     int rc = syncCopy(t->dev, t->mipPtr(mip), src, bytes, hipMemcpyHostToDevice);
-    t->quadValid = false;                      // everything submitted has completed: later submissions see the new contents
+    t->version.fetch_add(1);                   // everything submitted has completed: later submissions see the new contents
     return rc;
 }
 
@@ -624,14 +627,14 @@ int trhip_cmd_clear_texture_f32(trhip_cmdlist cl, trhip_texture tex, float value
         uint32_t bits;
         memcpy(&bits, &value, 4);
         size_t n = (size_t)(tex->totalBytes / 4);
-        cl->ops.push_back({ "", [p, n, bits, tex](hipStream_t s) { tex->quadValid = false; TRHIP_HIP(hipMemsetD32Async((hipDeviceptr_t)p, (int)bits, n, s)); return (int)TRHIP_OK; } });
+        cl->ops.push_back({ "", [p, n, bits](hipStream_t s) { TRHIP_HIP(hipMemsetD32Async((hipDeviceptr_t)p, (int)bits, n, s)); return (int)TRHIP_OK; } });
         cl->ops.back().kind = "clear_texture";
     } else {
         _Float16 h = (_Float16)value; // round-to-nearest-even
         uint16_t bits;
         memcpy(&bits, &h, 2);
         size_t n = (size_t)(tex->totalBytes / 2);
-        cl->ops.push_back({ "", [p, n, bits, tex](hipStream_t s) { tex->quadValid = false; TRHIP_HIP(hipMemsetD16Async((hipDeviceptr_t)p, bits, n, s)); return (int)TRHIP_OK; } });
+        cl->ops.push_back({ "", [p, n, bits](hipStream_t s) { TRHIP_HIP(hipMemsetD16Async((hipDeviceptr_t)p, bits, n, s)); return (int)TRHIP_OK; } });
         cl->ops.back().kind = "clear_texture";
     }
     return TRHIP_OK;
@@ -671,7 +674,7 @@ int trhip_cmd_copy_texture(trhip_cmdlist cl, trhip_texture dst, trhip_texture sr
     const void* sp = src->ptr;
     const uint64_t bytes = src->totalBytes;
     cl->hold(dst, true); cl->hold(src, false);
-    cl->ops.push_back({ "", [d, sp, bytes, dst](hipStream_t s) { dst->quadValid = false; TRHIP_HIP(hipMemcpyAsync(d, sp, (size_t)bytes, hipMemcpyDeviceToDevice, s)); return (int)TRHIP_OK; } });
+    cl->ops.push_back({ "", [d, sp, bytes](hipStream_t s) { TRHIP_HIP(hipMemcpyAsync(d, sp, (size_t)bytes, hipMemcpyDeviceToDevice, s)); return (int)TRHIP_OK; } });
     cl->ops.back().kind = "copy_texture";
     return TRHIP_OK;
 }
@@ -812,13 +815,16 @@ int trhip_queue_execute(trhip_device dev, const trhip_cmdlist* lists, uint32_t n
                 }
                 runTouched.insert(runTouched.end(), op.touched.begin(), op.touched.end());
                 stream = dev->sideStream;
-                while (mark < cl->useMarks.size() && cl->useMarks[mark].op <= oi) ++mark;   // ordered by the fork and by the side stream itself
+                for (; mark < cl->useMarks.size() && cl->useMarks[mark].op <= oi; ++mark)    // ordered by the fork and by the side stream itself
+                    if (cl->useMarks[mark].write && cl->useMarks[mark].version) cl->useMarks[mark].version->fetch_add(1);
             } else {
                 int rc = endRun();
                 if (rc != TRHIP_OK) return rc;
                 for (; mark < cl->useMarks.size() && cl->useMarks[mark].op <= oi; ++mark) {
-                    rc = waitForOwner(cl->useMarks[mark].ptr, cl->useMarks[mark].write);
+                    const trhip_cmdlist_t::UseMark& m = cl->useMarks[mark];
+                    rc = waitForOwner(m.ptr, m.write);
                     if (rc != TRHIP_OK) return rc;
+                    if (m.write && m.version) m.version->fetch_add(1);     // the contents change with this command
                 }
             }
             const bool prof = dev->profiling && !op.name.empty();

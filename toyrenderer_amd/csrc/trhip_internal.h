@@ -99,6 +99,17 @@ struct trhip_buffer_t
     // amplification records it wrote into this buffer (k_gpuculling.hip / k_basepass_as.hip).
     void* sidecar = nullptr;
     uint64_t sidecarBytes = 0;
+    // Bumped, in SUBMISSION order, by every command that writes the buffer (trhip_queue_execute) and by uploads:
+    // derived data (the instance cull cache below, the HZB footprint-min table) records the version it was built
+    // from and is rebuilt when that is no longer the current one.
+    std::atomic<uint64_t> version{1};
+    // Instance buffers only: the INSTANCE CULL CACHE (k_gpuculling.hip), a compact SoA restatement of what the
+    // instance cull reads per instance (world-space bounding sphere, max scale, LOD table) -- 88 B instead of the
+    // 300 B of AoS instance + mesh records it would otherwise pull through HBM every frame.
+    void* cullCache = nullptr;
+    uint64_t cullCacheBytes = 0;
+    uint64_t cullCacheInstVersion = 0, cullCacheMeshVersion = 0;
+    const void* cullCacheMesh = nullptr;
     std::atomic<int> rc{1};
 };
 
@@ -117,13 +128,13 @@ struct trhip_texture_t
     // Back-end private companion of an R16F min-HZB: the FOOTPRINT-MIN TABLE (k_hzb.hip).  For every mip and
     // every possible bilinear footprint origin (x0,y0) in [-1,w-1]x[-1,h-1] it holds the min of the 2x2
     // edge-clamped footprint, so the meshlet cull kernel resolves SampleLevel(min-reduction) with ONE 2-byte
-    // load.  quadValid is flipped on the host in SUBMISSION order (inside the ops' launch lambdas): false by
-    // everything that writes the texture, true by the table build.
+    // load.  It is current while quadBuiltVersion == version (see trhip_buffer_t::version).
     void* quad = nullptr;
     uint64_t quadBytes = 0;
     uint32_t quadOffset[16] = {};              // first entry of mip k; mip k has (w_k + 1) * (h_k + 1) entries
     uint32_t quadTotal = 0;
-    std::atomic<bool> quadValid{false};
+    uint64_t quadBuiltVersion = 0;
+    std::atomic<uint64_t> version{1};
     std::atomic<int> rc{1};
 
     uint32_t mipW(uint32_t k) const { return (width >> k) ? (width >> k) : 1u; }
@@ -174,9 +185,9 @@ struct trhip_cmdlist_t
 
     // Which allocations each command uses (recorded by hold()): checked against the side stream's runs
     // when the list is executed.
-    struct UseMark { size_t op; const void* ptr; bool write; };
+    struct UseMark { size_t op; const void* ptr; bool write; std::atomic<uint64_t>* version; };
     std::vector<UseMark> useMarks;
-    void use(const void* ptr, size_t op, bool write) { if (ptr) useMarks.push_back({ op, ptr, write }); }
+    void use(const void* ptr, size_t op, bool write, std::atomic<uint64_t>* version = nullptr) { if (ptr) useMarks.push_back({ op, ptr, write, version }); }
 
     void* scratchAlloc(size_t bytes);       // device memory valid until the list is re-opened/released
     void* scratchAllocSide(size_t bytes);   // same, from an arena only side-stream ops use (they are in order among themselves)
