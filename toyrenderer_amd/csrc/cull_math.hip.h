@@ -29,6 +29,35 @@ __device__ __forceinline__ float div_(float a, float b) { return a / b; }
 #endif
 __device__ __forceinline__ float clamp_(float x, float lo, float hi) { return min_(max_(x, lo), hi); }
 
+// Two independent fp32 values in one 64-bit register pair: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 process both
+// in one issue slot (the hot kernel is VALU-issue bound).  Every packed operation below is the same IEEE operation
+// on each component as its scalar counterpart, so results do not change.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat2(float x) { return v2f{ x, x }; }
+
+// Correctly rounded a / b per component (== the compiler's IEEE fdiv expansion: v_div_scale, v_rcp, Newton steps,
+// v_div_fmas, v_div_fixup) with the six fma / mul steps of the two divisions issued as packed instructions.
+__device__ __forceinline__ v2f div2(v2f n, v2f d)
+{
+#ifdef TR_EXPERIMENT_FAST_MATH
+    return v2f{ n.x * __builtin_amdgcn_rcpf(d.x), n.y * __builtin_amdgcn_rcpf(d.y) };
+#else
+    bool vccX, vccY, unused;
+    const v2f ds = { __builtin_amdgcn_div_scalef(n.x, d.x, false, &unused), __builtin_amdgcn_div_scalef(n.y, d.y, false, &unused) };
+    const v2f ns = { __builtin_amdgcn_div_scalef(n.x, d.x, true, &vccX), __builtin_amdgcn_div_scalef(n.y, d.y, true, &vccY) };
+    const v2f r = { __builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y) };
+    const v2f e0 = fma2(-ds, r, splat2(1.0f));
+    const v2f r1 = fma2(e0, r, r);
+    const v2f q = ns * r1;
+    const v2f e1 = fma2(-ds, q, ns);
+    const v2f q1 = fma2(e1, r1, q);
+    const v2f e2 = fma2(-ds, q1, ns);
+    return v2f{ __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e2.x, r1.x, q1.x, vccX), d.x, n.x),
+                __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e2.y, r1.y, q1.y, vccY), d.y, n.y) };
+#endif
+}
+
 __device__ __forceinline__ float dot3(F3 a, F3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
 
 __device__ __forceinline__ F3 cross3(F3 a, F3 b)
@@ -59,6 +88,33 @@ __device__ __forceinline__ F3 mulVec(F3 v, F3 r0, F3 r1, F3 r2)
 __device__ __forceinline__ F3 toView(F3 p, const M43& v)
 {
     F3 o = mulPoint(p, v);
+    o.z = -o.z;
+    return o;
+}
+
+// The same products with the x and y columns issued as packed pairs (per component the identical fma chain).
+struct M43P { v2f r0, r1, r2, r3; float z0, z1, z2, z3; };   // rows 0..3: (x, y) pairs + the z column
+struct M33P { v2f r0, r1, r2; float z0, z1, z2; };
+
+__device__ __forceinline__ M43P packM43(const M43& m)
+{
+    return { { m.r0.x, m.r0.y }, { m.r1.x, m.r1.y }, { m.r2.x, m.r2.y }, { m.r3.x, m.r3.y }, m.r0.z, m.r1.z, m.r2.z, m.r3.z };
+}
+__device__ __forceinline__ M33P rot(const M43P& m) { return { m.r0, m.r1, m.r2, m.z0, m.z1, m.z2 }; }
+
+__device__ __forceinline__ F3 mulPointP(F3 p, const M43P& m)          // == mulPoint
+{
+    const v2f xy = fma2(splat2(p.z), m.r2, fma2(splat2(p.y), m.r1, splat2(p.x) * m.r0)) + m.r3;
+    return { xy.x, xy.y, fma_(p.z, m.z2, fma_(p.y, m.z1, p.x * m.z0)) + m.z3 };
+}
+__device__ __forceinline__ F3 mulVecP(F3 v, const M33P& m)            // == mulVec
+{
+    const v2f xy = fma2(splat2(v.z), m.r2, fma2(splat2(v.y), m.r1, splat2(v.x) * m.r0));
+    return { xy.x, xy.y, fma_(v.z, m.z2, fma_(v.y, m.z1, v.x * m.z0)) };
+}
+__device__ __forceinline__ F3 toViewP(F3 p, const M43P& v)            // == toView
+{
+    F3 o = mulPointP(p, v);
     o.z = -o.z;
     return o;
 }
@@ -237,30 +293,30 @@ __device__ __forceinline__ OccQuad occlusionPrepareQuad(F3 c, float r, float nea
 {
     OccQuad o;
     o.accept = (c.z - nearPlane) < r;                                // :48-49
-    float crx = c.x * r, cry = c.y * r, crz = c.z * r;               // :53
-    float czr2 = fma_(c.z, c.z, -(r * r));                           // :54
-    float vx = sqrt_(fma_(c.x, c.x, czr2));                          // :56
-    float minx = div_(fma_(vx, c.x, -crz), fma_(vx, c.z, crx));      // :57
-    float maxx = div_(fma_(vx, c.x, crz), fma_(vx, c.z, -crx));      // :58
-    float vy = sqrt_(fma_(c.y, c.y, czr2));                          // :60
-    float miny = div_(fma_(vy, c.y, -crz), fma_(vy, c.z, cry));      // :61
-    float maxy = div_(fma_(vy, c.y, crz), fma_(vy, c.z, -cry));      // :62
-    float ax = clamp_(minx * P00, -1.0f, 1.0f);                      // :64-67
-    float ay = clamp_(miny * P11, -1.0f, 1.0f);
-    float az = clamp_(maxx * P00, -1.0f, 1.0f);
-    float aw = clamp_(maxy * P11, -1.0f, 1.0f);
-    ax = fma_(ax, 0.5f, 0.5f);                                       // :70-71 ClipXYToUV
-    ay = fma_(ay, -0.5f, 0.5f);
-    az = fma_(az, 0.5f, 0.5f);
-    aw = fma_(aw, -0.5f, 0.5f);
-    float width = (az - ax) * (float)h.width;                        // :73
-    float height = (aw - ay) * (float)h.height;                      // :74
-    int mip = hzbLevel(width, height, h.mips);                       // :75
-    float u = (ax + az) * 0.5f, v = (ay + aw) * 0.5f;                // :78
+    // the x and the y half of :53-78 are the same arithmetic on different inputs: computed as (x, y) pairs
+    const v2f cxy = { c.x, c.y };
+    const v2f cr = cxy * r;                                          // :53 cr.xy
+    const float crz = c.z * r;                                       // :53 cr.z
+    const float czr2 = fma_(c.z, c.z, -(r * r));                     // :54
+    const v2f vArg = fma2(cxy, cxy, splat2(czr2));
+    const v2f vv = { sqrt_(vArg.x), sqrt_(vArg.y) };                 // :56, :60  vx, vy
+    const v2f czz = splat2(c.z);
+    const v2f mn = div2(fma2(vv, cxy, splat2(-crz)), fma2(vv, czz, cr));    // :57, :61  minx, miny
+    const v2f mx = div2(fma2(vv, cxy, splat2(crz)), fma2(vv, czz, -cr));    // :58, :62  maxx, maxy
+    const v2f P = { P00, P11 };
+    const v2f sMin = mn * P, sMax = mx * P;                          // :64-67
+    v2f lo = { clamp_(sMin.x, -1.0f, 1.0f), clamp_(sMin.y, -1.0f, 1.0f) };       // (ax, ay)
+    v2f hi = { clamp_(sMax.x, -1.0f, 1.0f), clamp_(sMax.y, -1.0f, 1.0f) };       // (az, aw)
+    const v2f half = { 0.5f, -0.5f };
+    lo = fma2(lo, half, splat2(0.5f));                               // :70-71 ClipXYToUV
+    hi = fma2(hi, half, splat2(0.5f));
+    const v2f wh = (hi - lo) * v2f{ (float)h.width, (float)h.height };           // :73-74
+    int mip = hzbLevel(wh.x, wh.y, h.mips);                          // :75
+    const v2f uv = (lo + hi) * splat2(0.5f);                         // :78
     uint32_t mw = (h.width >> mip) ? (h.width >> mip) : 1u;
     uint32_t mh = (h.height >> mip) ? (h.height >> mip) : 1u;
-    float fx = fma_(u, (float)mw, -0.5f);
-    float fy = fma_(v, (float)mh, -0.5f);
+    const v2f f = fma2(uv, v2f{ (float)mw, (float)mh }, splat2(-0.5f));
+    const float fx = f.x, fy = f.y;
     float flx = __builtin_floorf(fx), fly = __builtin_floorf(fy);
     const int x0 = (int)flx, y0 = (int)fly;                          // in [-1, mw-1] x [-1, mh-1]
     // A zero weight drops the second column (row) from the footprint; that only changes the set of texels when the
@@ -306,6 +362,26 @@ __device__ __forceinline__ bool coneBackfacing(uint32_t packed, F3 cv, float r, 
     F3 axis = mulVec(t, view.r0, view.r1, view.r2);
     axis.z = -axis.z;
     return dot3(cv, axis) >= fma_(cutoff, sqrt_(dot3(cv, cv)), r);
+}
+
+// == coneBackfacing, with the byte decode, the two 3x3 products and two of the three normalisation divisions packed
+__device__ __forceinline__ bool coneBackfacingP(uint32_t packed, F3 cv, float r, const M33P& adj, const M33P& viewRot)
+{
+    const float rc = 0x1.010102p-8f;         // RN(1/255), see u8Unorm
+    const v2f x01 = { (float)(packed & 0xFFu), (float)((packed >> 8) & 0xFFu) };
+    const v2f x23 = { (float)((packed >> 16) & 0xFFu), (float)(packed >> 24) };
+    const v2f q01i = x01 * rc, q23i = x23 * rc;
+    const v2f q01 = fma2(fma2(-q01i, splat2(255.0f), x01), splat2(rc), q01i);      // (q0, q1)
+    const v2f q23 = fma2(fma2(-q23i, splat2(255.0f), x23), splat2(rc), q23i);      // (q2, cutoff)
+    const v2f a01 = fma2(q01, splat2(2.0f), splat2(-1.0f));
+    const F3 a = { a01.x, a01.y, fma_(q23.x, 2.0f, -1.0f) };
+    F3 t = mulVecP(a, adj);
+    const float len = sqrt_(dot3(t, t));
+    const v2f txy = div2(v2f{ t.x, t.y }, splat2(len));                            // normalize = v / length
+    t = { txy.x, txy.y, div_(t.z, len) };
+    F3 axis = mulVecP(t, viewRot);
+    axis.z = -axis.z;
+    return dot3(cv, axis) >= fma_(q23.y, sqrt_(dot3(cv, cv)), r);
 }
 
 __device__ __forceinline__ M43 loadM43(const interop::Matrix& m)

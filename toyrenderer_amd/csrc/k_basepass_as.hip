@@ -49,12 +49,24 @@ constexpr uint32_t kSlowCap = 64;                // per wave and batch: lookups 
 
 struct RecordInfo                                 // per-record invariants parked in LDS (96 B)
 {
-    float w[12];                                  // world matrix rows 0..3, xyz
-    float adj[9];                                 // MakeAdjugateMatrix rows
+    float wxy[8];                                 // world matrix rows 0..3: (x, y) pairs (8-byte aligned: read as packed operands)
+    float wz[4];                                  //                         z column
+    float adjxy[6];                               // MakeAdjugateMatrix rows 0..2: (x, y) pairs
+    float adjz[3];                                //                               z column
     float maxScale;
     uint32_t meshletBase;                         // m_MeshletDataBufferIdx + m_MeshletGroupOffset
     uint32_t count;                               // lanes with meshletIdx < m_NumMeshlets (0..32)
 };
+
+__device__ __forceinline__ cm::M43P worldOf(const RecordInfo& ri)
+{
+    return { { ri.wxy[0], ri.wxy[1] }, { ri.wxy[2], ri.wxy[3] }, { ri.wxy[4], ri.wxy[5] }, { ri.wxy[6], ri.wxy[7] },
+             ri.wz[0], ri.wz[1], ri.wz[2], ri.wz[3] };
+}
+__device__ __forceinline__ cm::M33P adjugateOf(const RecordInfo& ri)
+{
+    return { { ri.adjxy[0], ri.adjxy[1] }, { ri.adjxy[2], ri.adjxy[3] }, { ri.adjxy[4], ri.adjxy[5] }, ri.adjz[0], ri.adjz[1], ri.adjz[2] };
+}
 
 struct MeshletCullArgs
 {
@@ -160,6 +172,8 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t half = lane >> 5, sub = lane & 31u;
     const cm::M43 V = cm::loadM43(a.k.m_WorldToView);
+    const cm::M43P VP = cm::packM43(V);
+    const cm::M33P VR = cm::rot(VP);
     RecordInfo* s_rec = s_recAll[wave];
     uint32_t* s_gIdx = s_gIdxAll[wave];
 
@@ -194,9 +208,13 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
             RecordInfo ri;
             ri.count = 0; ri.meshletBase = 0; ri.maxScale = 0.f;
 #pragma unroll
-            for (int i = 0; i < 12; ++i) ri.w[i] = 0.f;
+            for (int i = 0; i < 8; ++i) ri.wxy[i] = 0.f;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) ri.adj[i] = 0.f;
+            for (int i = 0; i < 4; ++i) ri.wz[i] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ri.adjxy[i] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) ri.adjz[i] = 0.f;
             const uint32_t e = sbBase + (lane >> 1) * 2 * numWaves + 2 * waveId + (lane & 1);
             const uint32_t g = e < G ? (usePerm ? a.perm[e] : e) : 0xFFFFFFFFu;
             s_gIdx[lane] = g;
@@ -210,15 +228,15 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
                 const uint32_t lodIdx = rec.m_MeshLOD < kMaxNumMeshLODs ? rec.m_MeshLOD : kMaxNumMeshLODs - 1u;
                 const MeshLODData lod = a.meshData[inst.m_MeshDataIdx].m_MeshLODDatas[lodIdx];
                 const cm::F3 r0 = { w0.x, w0.y, w0.z }, r1 = { w1.x, w1.y, w1.z }, r2 = { w2.x, w2.y, w2.z };
-                ri.w[0] = w0.x; ri.w[1] = w0.y; ri.w[2] = w0.z;
-                ri.w[3] = w1.x; ri.w[4] = w1.y; ri.w[5] = w1.z;
-                ri.w[6] = w2.x; ri.w[7] = w2.y; ri.w[8] = w2.z;
-                ri.w[9] = w3.x; ri.w[10] = w3.y; ri.w[11] = w3.z;
+                ri.wxy[0] = w0.x; ri.wxy[1] = w0.y; ri.wz[0] = w0.z;
+                ri.wxy[2] = w1.x; ri.wxy[3] = w1.y; ri.wz[1] = w1.z;
+                ri.wxy[4] = w2.x; ri.wxy[5] = w2.y; ri.wz[2] = w2.z;
+                ri.wxy[6] = w3.x; ri.wxy[7] = w3.y; ri.wz[3] = w3.z;
                 ri.maxScale = cm::maxScale(r0, r1, r2);                              // toyrenderer_common.hlsli:134-140
                 const cm::F3 a0 = cm::cross3(r1, r2), a1 = cm::cross3(r2, r0), a2 = cm::cross3(r0, r1); // :124-132
-                ri.adj[0] = a0.x; ri.adj[1] = a0.y; ri.adj[2] = a0.z;
-                ri.adj[3] = a1.x; ri.adj[4] = a1.y; ri.adj[5] = a1.z;
-                ri.adj[6] = a2.x; ri.adj[7] = a2.y; ri.adj[8] = a2.z;
+                ri.adjxy[0] = a0.x; ri.adjxy[1] = a0.y; ri.adjz[0] = a0.z;
+                ri.adjxy[2] = a1.x; ri.adjxy[3] = a1.y; ri.adjz[1] = a1.z;
+                ri.adjxy[4] = a2.x; ri.adjxy[5] = a2.y; ri.adjz[2] = a2.z;
                 // lanes with meshletIdx = groupOffset + lane < numMeshlets (basepass.hlsl:62-63)
                 const uint32_t off = rec.m_MeshletGroupOffset;
                 uint32_t cnt = lod.m_NumMeshlets > off ? lod.m_NumMeshlets - off : 0u;
@@ -261,10 +279,9 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
             const float4 sphere = odd ? make_float4(r0, r1, r2, r3) : make_float4(slot.a.x, slot.a.y, slot.a.z, slot.a.w);
             const uint32_t cone = __float_as_uint(odd ? slot.b.x : r0);
             bool vis = myMeshlet < ri.count;
-            const cm::M43 W = { { ri.w[0], ri.w[1], ri.w[2] }, { ri.w[3], ri.w[4], ri.w[5] },
-                                { ri.w[6], ri.w[7], ri.w[8] }, { ri.w[9], ri.w[10], ri.w[11] } };
-            const cm::F3 cw = cm::mulPoint({ sphere.x, sphere.y, sphere.z }, W);                   // :67
-            const cm::F3 cv = cm::toView(cw, V);                                                   // :68-69
+            const cm::M43P W = worldOf(ri);
+            const cm::F3 cw = cm::mulPointP({ sphere.x, sphere.y, sphere.z }, W);                  // :67
+            const cm::F3 cv = cm::toViewP(cw, VP);                                                 // :68-69
             const float rad = sphere.w * ri.maxScale;                                              // :71
             if (FRUSTUM)
                 vis &= cm::frustumVisible(cv, rad, a.k.m_Frustum.x, a.k.m_Frustum.y, a.k.m_Frustum.z, a.k.m_Frustum.w); // :73
@@ -287,8 +304,7 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
                 slot = loadMeshletChunks(a.meshlets, s_rec[rn].meshletBase, s_rec[rn].count, sub);
             }
             if (CONE)                                                                              // :90-108
-                vis &= !cm::coneBackfacing(cone, cv, rad, { ri.adj[0], ri.adj[1], ri.adj[2] },
-                                           { ri.adj[3], ri.adj[4], ri.adj[5] }, { ri.adj[6], ri.adj[7], ri.adj[8] }, V);
+                vis &= !cm::coneBackfacingP(cone, cv, rad, adjugateOf(ri), VR);
             TR_STAMP(4);   // prefetch issue + cone
             if (OCCLUSION && !TABLE)
                 vis &= cm::occlusionResolve(os, row0, row1);
@@ -349,15 +365,12 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
                     const float4* p = reinterpret_cast<const float4*>(a.meshlets + ri.meshletBase);
                     const float4 sphere = p[2u * m];
                     const uint32_t cone = __float_as_uint(p[2u * m + 1u].x);
-                    const cm::M43 W = { { ri.w[0], ri.w[1], ri.w[2] }, { ri.w[3], ri.w[4], ri.w[5] },
-                                        { ri.w[6], ri.w[7], ri.w[8] }, { ri.w[9], ri.w[10], ri.w[11] } };
-                    const cm::F3 cv = cm::toView(cm::mulPoint({ sphere.x, sphere.y, sphere.z }, W), V);
+                    const cm::F3 cv = cm::toViewP(cm::mulPointP({ sphere.x, sphere.y, sphere.z }, worldOf(ri)), VP);
                     const float rad = sphere.w * ri.maxScale;
                     bool vis = true;
                     if (FRUSTUM) vis &= cm::frustumVisible(cv, rad, a.k.m_Frustum.x, a.k.m_Frustum.y, a.k.m_Frustum.z, a.k.m_Frustum.w);
                     vis &= cm::occlusionVisible(cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb);
-                    if (CONE) vis &= !cm::coneBackfacing(cone, cv, rad, { ri.adj[0], ri.adj[1], ri.adj[2] }, { ri.adj[3], ri.adj[4], ri.adj[5] },
-                                                         { ri.adj[6], ri.adj[7], ri.adj[8] }, V);
+                    if (CONE) vis &= !cm::coneBackfacingP(cone, cv, rad, adjugateOf(ri), VR);
                     return vis;
                 };
                 if (nSlow <= kSlowCap) {                                             // patch single bits
