@@ -119,8 +119,10 @@ __device__ __forceinline__ MeshletRegs loadMeshletChunks(const MeshletData* mesh
     const uint32_t nChunks = count * 2u;
     const uint32_t ja = sub < nChunks ? sub : 0u, jb = 32u + sub < nChunks ? 32u + sub : 0u;
     MeshletRegs m;
-    m.a = p[ja];                                                                     // basepass.hlsl:65
-    m.b = p[jb];
+    // basepass.hlsl:65.  Non-temporal: the 1.8 GB meshlet stream is read once and must not evict the HZB
+    // footprint table and the per-record data from the 4 MB L2s (measured -3 % on the kernel).
+    m.a = __builtin_nontemporal_load(p + ja);
+    m.b = __builtin_nontemporal_load(p + jb);
     return m;
 }
 
