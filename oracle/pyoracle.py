@@ -111,6 +111,8 @@ def lib() -> C.CDLL:
         L.orc_max_scale.argtypes = [C.c_void_p]
         L.orc_sphere_to_world.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_to_view.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_occlusion_footprints.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_float, C.c_float,
+                                               C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_unpack_cone_view.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_select_lod.restype = C.c_uint32
         L.orc_select_lod.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_uint32, C.c_float]
@@ -260,6 +262,21 @@ def meshlet_cull(consts: np.ndarray, instances, meshData, meshlets, records, g0:
 
 def update_instance_consts(nodes, primToNode, instances):
     lib().orc_update_instance_consts(_p(nodes), _p(primToNode), _p(instances), len(instances))
+
+
+def occlusion_footprints(centres: np.ndarray, radii: np.ndarray, view: dict, hzb_dims) -> np.ndarray:
+    """Test helper: per sphere (world-space centre, identity instance transform) {level, x0, y0, fracX == 0, fracY == 0}
+    of its occlusion lookup (tr_oracle.c orc_occlusion_footprints)."""
+    c = np.ascontiguousarray(centres, np.float32).reshape(-1, 3)
+    r = np.ascontiguousarray(radii, np.float32).reshape(-1)
+    assert len(c) == len(r)
+    V = np.ascontiguousarray(view["worldToView"], np.float32).reshape(4, 4)
+    P = np.ascontiguousarray(view["viewToClip"], np.float32).reshape(4, 4)
+    hw, hh = int(hzb_dims[0]), int(hzb_dims[1])
+    mips = max(hw, hh).bit_length()
+    out = np.zeros((len(c), 5), np.int32)
+    lib().orc_occlusion_footprints(_p(c), _p(r), len(c), _p(V), float(P[0, 0]), float(P[1, 1]), hw, hh, mips, _p(out))
+    return out
 
 
 class FrameResult:

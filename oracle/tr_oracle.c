@@ -178,14 +178,10 @@ float orc_sample_hzb_min(const OrcHZB* hzb, float u, float v, float level)
     return sample_hzb_min_mip(hzb, u, v, mip);
 }
 
-/* culling.hlsli:36-82 (Mara & McGuire 2013 sphere bounds; Q6 y flip kept). */
-int orc_occlusion_cull(const float c[3], float radius, float nearPlane, float P00, float P11, const OrcHZB* hzb)
+/* culling.hlsli:53-78: screen-space bounds of the sphere -> HZB level and sample position. */
+static void occlusion_sample_position(const float c[3], float r, float P00, float P11,
+                                      uint32_t hzbW, uint32_t hzbH, uint32_t mips, float* u, float* v, int* level)
 {
-    /* :48-49 trivially accept if the sphere intersects the near plane */
-    if ((c[2] - nearPlane) < radius)
-        return 1;
-
-    float r = radius;
     float cr[3] = { c[0] * r, c[1] * r, c[2] * r };                 /* :53 */
     float czr2 = fmaf(c[2], c[2], -(r * r));                        /* :54 */
 
@@ -208,14 +204,49 @@ int orc_occlusion_cull(const float c[3], float radius, float nearPlane, float P0
     az = fmaf(az, 0.5f, 0.5f);
     aw = fmaf(aw, -0.5f, 0.5f);
 
-    float width = (az - ax) * (float)hzb->width;                    /* :73 */
-    float height = (aw - ay) * (float)hzb->height;                  /* :74 */
-    int level = orc_hzb_level(width, height, hzb->mips);            /* :75 */
+    float width = (az - ax) * (float)hzbW;                          /* :73 */
+    float height = (aw - ay) * (float)hzbH;                         /* :74 */
+    *level = orc_hzb_level(width, height, mips);                    /* :75 */
+    *u = (ax + az) * 0.5f;                                          /* :78 */
+    *v = (ay + aw) * 0.5f;
+}
 
-    float u = (ax + az) * 0.5f, v = (ay + aw) * 0.5f;               /* :78 */
+/* culling.hlsli:36-82 (Mara & McGuire 2013 sphere bounds; Q6 y flip kept). */
+int orc_occlusion_cull(const float c[3], float radius, float nearPlane, float P00, float P11, const OrcHZB* hzb)
+{
+    /* :48-49 trivially accept if the sphere intersects the near plane */
+    if ((c[2] - nearPlane) < radius)
+        return 1;
+
+    float r = radius, u, v;
+    int level;
+    occlusion_sample_position(c, r, P00, P11, hzb->width, hzb->height, hzb->mips, &u, &v, &level);
     float depth = sample_hzb_min_mip(hzb, u, v, level);
     float depthSphere = nearPlane / (c[2] - r);                     /* :79 */
     return depthSphere >= depth;                                    /* :81 */
+}
+
+/* Test helper (not part of the path): where the occlusion test of each sphere samples the HZB.  For sphere i
+ * (world-space centre, radius; identity instance transform) out[5i..] = { level, x0, y0, fracX == 0, fracY == 0 }
+ * with (x0, y0) = floor(uv * mipDim - 0.5), the origin of the bilinear footprint (sample_hzb_min_mip).  Used to
+ * construct scenes whose lookups have zero bilinear weights (tests/test_gpu_parity.py). */
+void orc_occlusion_footprints(const float* centres, const float* radii, uint32_t n, const OrcMatrix* worldToView,
+                              float P00, float P11, uint32_t hzbW, uint32_t hzbH, uint32_t mips, int32_t* out)
+{
+    for (uint32_t i = 0; i < n; ++i) {
+        float cv[3], u, v;
+        int level;
+        orc_to_view(&centres[3 * i], worldToView, cv);
+        occlusion_sample_position(cv, radii[i], P00, P11, hzbW, hzbH, mips, &u, &v, &level);
+        uint32_t mw = (hzbW >> level) ? (hzbW >> level) : 1u, mh = (hzbH >> level) ? (hzbH >> level) : 1u;
+        float fx = fmaf(u, (float)mw, -0.5f), fy = fmaf(v, (float)mh, -0.5f);
+        float flx = floorf(fx), fly = floorf(fy);
+        out[5 * i + 0] = level;
+        out[5 * i + 1] = (int32_t)flx;
+        out[5 * i + 2] = (int32_t)fly;
+        out[5 * i + 3] = !((fx - flx) > 0.0f);
+        out[5 * i + 4] = !((fy - fly) > 0.0f);
+    }
 }
 
 /* culling.hlsli:84-87 */

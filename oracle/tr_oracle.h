@@ -175,6 +175,10 @@ void orc_instance_cull(const OrcGPUCullingPassConstants* k, int lateCull,
                        uint32_t maxGroups,
                        uint32_t* validRecords);
 
+/* Test helper: HZB level and bilinear footprint origin of each sphere's occlusion lookup (see tr_oracle.c). */
+void orc_occlusion_footprints(const float* centres, const float* radii, uint32_t n, const OrcMatrix* worldToView,
+                              float P00, float P11, uint32_t hzbW, uint32_t hzbH, uint32_t mips, int32_t* out);
+
 /* CS_BuildLateCullIndirectArgs (gpuculling.hlsl:182-195), Q1: divides by 64. */
 void orc_build_late_args(uint32_t lateCount, uint32_t out[3]);
 

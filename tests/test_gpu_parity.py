@@ -267,3 +267,91 @@ def test_deterministic_across_runs(dev, oracle):
         assert np.array_equal(outs[1][0], outs[2][0]) and np.array_equal(outs[1][2], outs[2][2])
     finally:
         drv.release(); gs.release()
+
+
+def _zero_weight_lookup_scene(oracle, view, n_dense_meshes=64, n_sparse_meshes=128, seed=11):
+    """Meshlets whose HZB lookup has a ZERO bilinear weight (fractional texel coordinate exactly 0 with a second
+    column / row that survives edge clamping): the case the footprint-min table of the meshlet cull kernel cannot
+    serve (DESIGN.md "HZB lookup = one 2-byte load").  They are about 1 in 10^4 of random spheres, so candidates
+    are screened with the oracle (orc_occlusion_footprints).  Scene: `n_dense_meshes` meshes of 32 such meshlets
+    (every lane of every step defers -> the per-wave list overflows) + `n_sparse_meshes` meshes with one such
+    meshlet among 31 ordinary ones (deferred lookups patched one by one).  Identity instance transforms."""
+    rng = np.random.default_rng(seed)
+    vd = view.as_dict()
+    hw, hh = view.hzb_dims
+    need = 32 * n_dense_meshes + n_sparse_meshes
+    slow_c, slow_r = [], []
+    ordinary = None
+    have = 0
+    for _ in range(40):
+        n = 4_000_000
+        z = rng.uniform(8, 120, n).astype(np.float32)
+        c = np.stack([rng.uniform(-0.5, 0.5, n) * z, rng.uniform(-0.28, 0.28, n) * z, -z], 1).astype(np.float32)   # the camera looks down -z
+        r = (rng.uniform(0.004, 0.05, n) * (z / 20)).astype(np.float32)
+        fp = oracle.occlusion_footprints(c, r, vd, (hw, hh))
+        mw, mh = np.maximum(hw >> fp[:, 0], 1), np.maximum(hh >> fp[:, 0], 1)
+        slow = ((fp[:, 3] == 1) & (fp[:, 1] >= 0) & (fp[:, 1] + 1 < mw)) | ((fp[:, 4] == 1) & (fp[:, 2] >= 0) & (fp[:, 2] + 1 < mh))
+        slow_c.append(c[slow]); slow_r.append(r[slow])
+        have += int(slow.sum())
+        if ordinary is None:
+            keep = np.nonzero(~slow)[0][:31 * n_sparse_meshes]
+            ordinary = (c[keep], r[keep])
+        if have >= need:
+            break
+    assert have >= need, f"only {have} zero-weight lookups found"
+    sc, sr = np.concatenate(slow_c)[:need], np.concatenate(slow_r)[:need]
+    num_meshes = n_dense_meshes + n_sparse_meshes
+    ml = np.zeros(32 * num_meshes, I.MeshletData)
+    centres = np.zeros((32 * num_meshes, 3), np.float32)
+    radii = np.zeros(32 * num_meshes, np.float32)
+    centres[:32 * n_dense_meshes] = sc[:32 * n_dense_meshes]
+    radii[:32 * n_dense_meshes] = sr[:32 * n_dense_meshes]
+    for k in range(n_sparse_meshes):
+        base = 32 * (n_dense_meshes + k)
+        pos = int(rng.integers(0, 32))
+        others = [j for j in range(32) if j != pos]
+        centres[base + pos], radii[base + pos] = sc[32 * n_dense_meshes + k], sr[32 * n_dense_meshes + k]
+        centres[[base + j for j in others]] = ordinary[0][31 * k:31 * (k + 1)]
+        radii[[base + j for j in others]] = ordinary[1][31 * k:31 * (k + 1)]
+    ml["m_BoundingSphere"][:, :3] = centres
+    ml["m_BoundingSphere"][:, 3] = radii
+    ml["m_ConeAxisAndCutoff"] = rng.integers(0, 2 ** 32, len(ml), dtype=np.uint64).astype(np.uint32)
+    md = np.zeros(num_meshes, I.MeshData)
+    md["m_BoundingSphere"] = np.array([0, 0, 0, 1000.0], np.float32)      # around the camera: passes every instance-level test
+    md["m_NumLODs"] = 1
+    md["m_MeshLODDatas"]["m_MeshletDataBufferIdx"][:, 0] = np.arange(num_meshes, dtype=np.uint32) * 32
+    md["m_MeshLODDatas"]["m_NumMeshlets"][:, 0] = 32
+    inst = np.zeros(num_meshes, I.BasePassInstanceConstants)
+    inst["m_WorldMatrix"] = np.eye(4, dtype=np.float32).reshape(inst["m_WorldMatrix"].shape[1:])
+    inst["m_PrevWorldMatrix"] = inst["m_WorldMatrix"]
+    inst["m_MeshDataIdx"] = np.arange(num_meshes, dtype=np.uint32)
+    return inst, md, ml
+
+
+def test_zero_weight_hzb_lookups_take_the_texel_path(dev, oracle):
+    """The footprint-min table path of the early meshlet cull (record capacity >= 2^19) on lookups it must defer."""
+    from toyrenderer_amd.frame import FrameDriver, GpuScene
+    view = synth.make_view(render=(1920, 1080))
+    inst, md, ml = _zero_weight_lookup_scene(oracle, view)
+    ids = np.arange(len(inst), dtype=np.uint32)
+    d_prev = synth.gen_depth(view, 120, seed=5, scale=2.0)
+    hzb = _oracle_hzb(oracle, view, d_prev)
+    cap = 1 << 19
+    gs = GpuScene(dev, inst, md, ml, ids, np.zeros(0, np.uint32))
+    drv = FrameDriver(dev, gs, view, record_capacity=cap, culling_flags=7)
+    _upload_hzb(drv, hzb)
+    drv.depth.upload_mip(0, d_prev)
+    try:
+        for frame in range(2):
+            drv.record()
+            drv.run()
+            got = drv.results()
+            scene = dict(instances=inst, meshData=md, meshlets=ml, opaqueIds=ids, alphaMaskIds=np.zeros(0, np.uint32))
+            ref = oracle.frame(scene, view.as_dict(), hzb, d_prev, cullingFlags=7, maxGroups=cap, record_capacity=cap)
+            _compare_frame(got, ref, slots=(0, 1))
+            assert int(ref.dispatchArgs[0][0]) == len(inst), "every instance submitted in the early phase"
+            vis = int(ref.drawArgs[0][0])
+            assert 0 < vis < 32 * len(inst), "the HZB decides: some of the deferred lookups pass, some fail"
+    finally:
+        drv.release()
+        gs.release()
