@@ -1,0 +1,37 @@
+// instance_cache.hip.h -- the INSTANCE CULL CACHE (trhip_buffer_t::cullCache of an instance buffer): a compact
+// SoA restatement, over instance ids, of what the cull passes read per instance.  Built by instanceCacheKernel
+// (k_gpuculling.hip) whenever the instance or the mesh buffer has been written since (version counters,
+// trhip_internal.h).  Same arithmetic as the direct path, so every cached value is bit-identical to what the
+// kernels would compute from the AoS records (BasePassInstanceConstants 144 B, MeshData 156 B).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "ShaderInterop.h"
+
+struct InstanceCullCache
+{
+    const float4* sphere;           // world-space bounding sphere: TransformBoundingSphereToWorld (gpuculling.hlsl:116)
+    const float4* world;            // [id][3]: world matrix rows 0..3, xyz, as 12 consecutive floats
+    const float* maxScale;          // toyrenderer_common.hlsli:134-140
+    const uint32_t* numLODs;
+    const uint32_t* numMeshlets;    // [id][kMaxNumMeshLODs]
+    const uint32_t* meshletBase;    // [id][kMaxNumMeshLODs]  m_MeshletDataBufferIdx
+    const float* error;             // [id][kMaxNumMeshLODs]
+};
+
+constexpr uint64_t kInstanceCacheBytesPerInstance = 16 + 48 + 4 + 4 + 3 * 4 * interop::kMaxNumMeshLODs;
+
+inline InstanceCullCache instanceCacheLayout(void* base, uint64_t n)
+{
+    char* p = (char*)base;
+    InstanceCullCache c;
+    c.sphere = (const float4*)p;            p += 16 * n;
+    c.world = (const float4*)p;             p += 48 * n;
+    c.maxScale = (const float*)p;           p += 4 * n;
+    c.numLODs = (const uint32_t*)p;         p += 4 * n;
+    c.numMeshlets = (const uint32_t*)p;     p += 4ull * interop::kMaxNumMeshLODs * n;
+    c.meshletBase = (const uint32_t*)p;     p += 4ull * interop::kMaxNumMeshLODs * n;
+    c.error = (const float*)p;
+    return c;
+}

@@ -34,6 +34,7 @@
 #include <type_traits>
 
 #include "cull_math.hip.h"
+#include "instance_cache.hip.h"
 #include "trhip_internal.h"
 
 using namespace interop;
@@ -90,7 +91,9 @@ struct MeshletCullArgs
     // optional processing order written by the instance pass into the record buffer's sidecar
     // (k_gpuculling.hip): {valid, count} header + a permutation of [0, count) sorted by screen tile
     const uint32_t* permHeader;
-    const uint32_t* perm;
+    const uint4* perm;                            // {record index, instance, lod, group offset} in processing order
+    InstanceCullCache cache;                      // world matrix, max scale, LOD table per instance (instance_cache.hip.h)
+    uint32_t numInstances;
 };
 
 __device__ __forceinline__ uint32_t groupCount(const MeshletCullArgs& a)
@@ -197,6 +200,16 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
     const uint32_t waveId = blockIdx.x * kWaves + wave;
     const uint32_t superSize = numWaves * kBatch;
     const uint32_t numSuper = (G + superSize - 1) / superSize;
+    // The batch entry of lane l = the record of step l/2, half l&1, as {record index, instance, lod, group offset}
+    // (0xFFFFFFFF = none): from the permuted copy the instance pass wrote, or from the record buffer itself.
+    auto loadEntry = [&](uint32_t sbBase_) -> uint4 {
+        const uint32_t e = sbBase_ + (lane >> 1) * 2 * numWaves + 2 * waveId + (lane & 1);
+        if (e >= G) return make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+        if (usePerm) return a.perm[e];
+        const MeshletAmplificationData rec = a.records[e];
+        return make_uint4(e, rec.m_InstanceConstIdx, rec.m_MeshLOD, rec.m_MeshletGroupOffset);
+    };
+    uint4 entry = loadEntry(0u);
     for (uint32_t sb = 0; sb < numSuper; ++sb) {
         const uint32_t sbBase = sb * superSize;
         if (sbBase + 2 * waveId >= G) break;                                         // nothing left for this wave
@@ -205,7 +218,8 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
         uint32_t nSteps = (remaining + 2 * numWaves - 1) / (2 * numWaves);
         nSteps = nSteps < kSteps ? (nSteps + 1u) & ~1u : kSteps;
         TR_STAMP(0);   // between batches
-        // ---- prologue: lane l resolves the record of step l/2, half l&1 (basepass.hlsl:52-58) ---
+        // ---- prologue: lane l resolves its record (basepass.hlsl:52-58) through the instance cull cache: ONE
+        //      level of dependent loads here -- the entry itself was fetched while the previous batch ran ------
         {
             RecordInfo ri;
             ri.count = 0; ri.meshletBase = 0; ri.maxScale = 0.f;
@@ -217,33 +231,32 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
             for (int i = 0; i < 6; ++i) ri.adjxy[i] = 0.f;
 #pragma unroll
             for (int i = 0; i < 3; ++i) ri.adjz[i] = 0.f;
-            const uint32_t e = sbBase + (lane >> 1) * 2 * numWaves + 2 * waveId + (lane & 1);
-            const uint32_t g = e < G ? (usePerm ? a.perm[e] : e) : 0xFFFFFFFFu;
+            const uint4 cur = entry;
+            entry = loadEntry(sbBase + superSize);                                   // next batch's entry: in flight during this batch
+            const uint32_t g = cur.x < G ? cur.x : 0xFFFFFFFFu;
             s_gIdx[lane] = g;
             if (g < G) {
-                const MeshletAmplificationData rec = a.records[g];
-                const BasePassInstanceConstants& inst = a.instances[rec.m_InstanceConstIdx];
-                const float4 w0 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[0]);
-                const float4 w1 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[1]);
-                const float4 w2 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[2]);
-                const float4 w3 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[3]);
-                const uint32_t lodIdx = rec.m_MeshLOD < kMaxNumMeshLODs ? rec.m_MeshLOD : kMaxNumMeshLODs - 1u;
-                const MeshLODData lod = a.meshData[inst.m_MeshDataIdx].m_MeshLODDatas[lodIdx];
-                const cm::F3 r0 = { w0.x, w0.y, w0.z }, r1 = { w1.x, w1.y, w1.z }, r2 = { w2.x, w2.y, w2.z };
-                ri.wxy[0] = w0.x; ri.wxy[1] = w0.y; ri.wz[0] = w0.z;
-                ri.wxy[2] = w1.x; ri.wxy[3] = w1.y; ri.wz[1] = w1.z;
-                ri.wxy[4] = w2.x; ri.wxy[5] = w2.y; ri.wz[2] = w2.z;
-                ri.wxy[6] = w3.x; ri.wxy[7] = w3.y; ri.wz[3] = w3.z;
-                ri.maxScale = cm::maxScale(r0, r1, r2);                              // toyrenderer_common.hlsli:134-140
+                const uint32_t cid = cur.y < a.numInstances ? cur.y : 0u;            // never read outside the cache
+                const float4* wr = a.cache.world + 3ull * cid;
+                const float4 q0 = wr[0], q1 = wr[1], q2 = wr[2];
+                const uint32_t lodIdx = cur.z < kMaxNumMeshLODs ? cur.z : kMaxNumMeshLODs - 1u;
+                const uint32_t lodNumMeshlets = a.cache.numMeshlets[(uint64_t)cid * kMaxNumMeshLODs + lodIdx];
+                const uint32_t lodMeshletBase = a.cache.meshletBase[(uint64_t)cid * kMaxNumMeshLODs + lodIdx];
+                const cm::F3 r0 = { q0.x, q0.y, q0.z }, r1 = { q0.w, q1.x, q1.y }, r2 = { q1.z, q1.w, q2.x };
+                ri.wxy[0] = r0.x; ri.wxy[1] = r0.y; ri.wz[0] = r0.z;
+                ri.wxy[2] = r1.x; ri.wxy[3] = r1.y; ri.wz[1] = r1.z;
+                ri.wxy[4] = r2.x; ri.wxy[5] = r2.y; ri.wz[2] = r2.z;
+                ri.wxy[6] = q2.y; ri.wxy[7] = q2.z; ri.wz[3] = q2.w;
+                ri.maxScale = a.cache.maxScale[cid];                                 // toyrenderer_common.hlsli:134-140 (cached)
                 const cm::F3 a0 = cm::cross3(r1, r2), a1 = cm::cross3(r2, r0), a2 = cm::cross3(r0, r1); // :124-132
                 ri.adjxy[0] = a0.x; ri.adjxy[1] = a0.y; ri.adjz[0] = a0.z;
                 ri.adjxy[2] = a1.x; ri.adjxy[3] = a1.y; ri.adjz[1] = a1.z;
                 ri.adjxy[4] = a2.x; ri.adjxy[5] = a2.y; ri.adjz[2] = a2.z;
                 // lanes with meshletIdx = groupOffset + lane < numMeshlets (basepass.hlsl:62-63)
-                const uint32_t off = rec.m_MeshletGroupOffset;
-                uint32_t cnt = lod.m_NumMeshlets > off ? lod.m_NumMeshlets - off : 0u;
+                const uint32_t off = cur.w;
+                uint32_t cnt = lodNumMeshlets > off ? lodNumMeshlets - off : 0u;
                 cnt = cnt < 32u ? cnt : 32u;
-                const uint64_t base = (uint64_t)lod.m_MeshletDataBufferIdx + off;
+                const uint64_t base = (uint64_t)lodMeshletBase + off;
                 if (base + cnt > a.numMeshlets) cnt = 0;                             // never read outside the meshlet buffer
                 ri.count = cnt;
                 ri.meshletBase = (uint32_t)base;
@@ -748,10 +761,14 @@ int recordASMain(trhip::DispatchCtx& ctx)
     const uint64_t lcap = visList->byteSize / 4;
     a.listCapacity = lcap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)lcap;
     a.drawArgs = (uint32_t*)drawArgs->ptr;
-    if (records->sidecar && records->sidecarBytes >= 256 + (uint64_t)a.recordCapacity * 4) {
+    if (records->sidecar && records->sidecarBytes >= 256 + (uint64_t)a.recordCapacity * 16) {
         a.permHeader = (const uint32_t*)records->sidecar;
-        a.perm = a.permHeader + 64;
+        a.perm = (const uint4*)(a.permHeader + 64);
     }
+    rc = trhip::instanceCacheEnsure(instances);
+    if (rc != TRHIP_OK) return rc;
+    a.numInstances = (uint32_t)(instances->byteSize / sizeof(BasePassInstanceConstants));
+    a.cache = instanceCacheLayout(instances->cullCache, a.numInstances);
     a.maxBatches = (a.recordCapacity + kBatch - 1) / kBatch;
     a.batchSum = (uint32_t*)(a.recordCapacity >= (1u << 19) ? ctx.scratchSide((size_t)a.maxBatches * 4)   // only the list build uses it
                                                             : ctx.scratch((size_t)a.maxBatches * 4));
@@ -769,7 +786,11 @@ int recordASMain(trhip::DispatchCtx& ctx)
     trhip_texture_t* quadOwner = useTable ? hzb : nullptr;
     const bool table = useTable;
     if (quadOwner) ctx.cl->use(quadOwner->quad, ctx.cl->ops.size(), false);     // the kernel reads the table: ordered after a side-stream rebuild
-    ctx.emit("cull", [a, grid, flags, quadOwner, table](hipStream_t s) {
+    ctx.emit("cull", [a, grid, flags, quadOwner, table, instances, meshData](hipStream_t s) {
+        {                                                  // no-op unless the instance or mesh buffer was written since the cache was built
+            int crc = trhip::instanceCacheLaunchBuild(instances, meshData, s);
+            if (crc != TRHIP_OK) return crc;
+        }
         if (quadOwner) {                                   // no-op unless the HZB was written since its table was built
             int brc = trhip::hzbQuadLaunchBuild(quadOwner, s);
             if (brc != TRHIP_OK) return brc;

@@ -16,6 +16,7 @@
 // scratch per entry (A write, C read), 12 B per record (C).  Bound: HBM; the pass is <5 % of a
 // frame on the 100 M-meshlet config (DESIGN.md "Kernels").
 #include "cull_math.hip.h"
+#include "instance_cache.hip.h"
 #include "trhip_internal.h"
 
 using namespace interop;
@@ -27,32 +28,6 @@ constexpr uint32_t kBlock = 256;
 constexpr uint32_t kWordSubmit = 1u << 30;
 constexpr uint32_t kWordLate = 1u << 31;
 constexpr uint32_t kGroupMask = (1u << 27) - 1u;
-
-// Instance cull cache (trhip_buffer_t::cullCache): SoA over instance ids, built by instanceCacheKernel whenever
-// the instance or mesh buffer has been written since (version counters).  Same arithmetic as the direct path,
-// so the cached values are bit-identical to what classify() would compute from the AoS records.
-struct InstanceCullCache
-{
-    const float4* sphere;           // world-space bounding sphere: TransformBoundingSphereToWorld (gpuculling.hlsl:116)
-    const float* maxScale;          // toyrenderer_common.hlsli:134-140
-    const uint32_t* numLODs;
-    const uint32_t* numMeshlets;    // [id][kMaxNumMeshLODs]
-    const float* error;             // [id][kMaxNumMeshLODs]
-};
-
-constexpr uint64_t kCacheBytesPerInstance = 16 + 4 + 4 + 4 * kMaxNumMeshLODs + 4 * kMaxNumMeshLODs;
-
-InstanceCullCache cacheLayout(void* base, uint64_t n)
-{
-    char* p = (char*)base;
-    InstanceCullCache c;
-    c.sphere = (const float4*)p;            p += 16 * n;
-    c.maxScale = (const float*)p;           p += 4 * n;
-    c.numLODs = (const uint32_t*)p;         p += 4 * n;
-    c.numMeshlets = (const uint32_t*)p;     p += 4ull * kMaxNumMeshLODs * n;
-    c.error = (const float*)p;
-    return c;
-}
 
 struct InstanceCullArgs
 {
@@ -86,7 +61,7 @@ struct InstanceCullArgs
     uint32_t* tileCount;
     uint16_t* tileOf;               // per entry
     uint32_t* permHeader;
-    uint32_t* perm;
+    uint4* perm;                    // {record index, instance, lod, group offset}: the record itself, in processing order
     uint32_t permCapacity;
 };
 
@@ -104,25 +79,32 @@ __global__ __launch_bounds__(256) void instanceCacheKernel(const BasePassInstanc
     const uint32_t meshIdx = inst.m_MeshDataIdx;
     float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t numLODs = 0;
-    uint32_t nm[kMaxNumMeshLODs];
+    uint32_t nm[kMaxNumMeshLODs], mb[kMaxNumMeshLODs];
     float err[kMaxNumMeshLODs];
 #pragma unroll
-    for (uint32_t l = 0; l < kMaxNumMeshLODs; ++l) { nm[l] = 0; err[l] = 0.f; }
+    for (uint32_t l = 0; l < kMaxNumMeshLODs; ++l) { nm[l] = 0; mb[l] = 0; err[l] = 0.f; }
     if (meshIdx < numMeshes) {                                                       // never read outside the mesh table
         const MeshData& mesh = meshData[meshIdx];
         sph = *reinterpret_cast<const float4*>(&mesh.m_BoundingSphere);
         numLODs = mesh.m_NumLODs;
 #pragma unroll
-        for (uint32_t l = 0; l < kMaxNumMeshLODs; ++l) { nm[l] = mesh.m_MeshLODDatas[l].m_NumMeshlets; err[l] = mesh.m_MeshLODDatas[l].m_Error; }
+        for (uint32_t l = 0; l < kMaxNumMeshLODs; ++l) {
+            nm[l] = mesh.m_MeshLODDatas[l].m_NumMeshlets; mb[l] = mesh.m_MeshLODDatas[l].m_MeshletDataBufferIdx; err[l] = mesh.m_MeshLODDatas[l].m_Error;
+        }
     }
     const float ms = cm::maxScale(W.r0, W.r1, W.r2);
     const cm::F3 wc = cm::mulPoint({ sph.x, sph.y, sph.z }, W);                      // :116 TransformBoundingSphereToWorld
     const_cast<float4*>(c.sphere)[i] = make_float4(wc.x, wc.y, wc.z, sph.w * ms);
+    float4* wr = const_cast<float4*>(c.world) + 3ull * i;
+    wr[0] = make_float4(w0.x, w0.y, w0.z, w1.x);
+    wr[1] = make_float4(w1.y, w1.z, w2.x, w2.y);
+    wr[2] = make_float4(w2.z, w3.x, w3.y, w3.z);
     const_cast<float*>(c.maxScale)[i] = ms;
     const_cast<uint32_t*>(c.numLODs)[i] = numLODs;
 #pragma unroll
     for (uint32_t l = 0; l < kMaxNumMeshLODs; ++l) {
         const_cast<uint32_t*>(c.numMeshlets)[(uint64_t)i * kMaxNumMeshLODs + l] = nm[l];
+        const_cast<uint32_t*>(c.meshletBase)[(uint64_t)i * kMaxNumMeshLODs + l] = mb[l];
         const_cast<float*>(c.error)[(uint64_t)i * kMaxNumMeshLODs + l] = err[l];
     }
 }
@@ -384,7 +366,7 @@ __global__ __launch_bounds__(kBlock) void instanceEmitKernel(InstanceCullArgs a)
     if (groups != 0 && n >= kMinBinnedEntries) {                                    // slot range in the tile-sorted order
         const uint32_t p = atomicAdd(&a.tileCount[(uint32_t)a.tileOf[t] * kTileReplicas + (blockIdx.x % kTileReplicas)], groups);
         for (uint32_t i = 0; i < groups; ++i)
-            if (p + i < a.permCapacity) a.perm[p + i] = off + i;
+            if (p + i < a.permCapacity) a.perm[p + i] = make_uint4(off + i, id, lod, i * kNumThreadsPerWave);
     }
 }
 
@@ -480,30 +462,11 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
     if (nMax == 0) return TRHIP_OK;
 
     // instance cull cache: (re)built, in submission order, when the instance or the mesh buffer has been written
-    const uint64_t numInst = instances->byteSize / sizeof(BasePassInstanceConstants);
-    const uint64_t numMeshes = meshData->byteSize / sizeof(MeshData);
-    TRHIP_REQUIRE(numInst >= 1 && numInst <= 0xFFFFFFFFull && numMeshes <= 0xFFFFFFFFull, "%s: instance / mesh buffer sizes out of range", ctx.shaderName);
-    if (instances->cullCacheBytes < numInst * kCacheBytesPerInstance) {
-        TRHIP_HIP(hipSetDevice(ctx.cl->dev->index));
-        if (instances->cullCache) { rc = ctx.cl->dev->syncAll(); if (rc != TRHIP_OK) return rc; (void)hipFree(instances->cullCache); instances->cullCache = nullptr; instances->cullCacheBytes = 0; }
-        TRHIP_HIP(hipMalloc(&instances->cullCache, (size_t)(numInst * kCacheBytesPerInstance)));
-        instances->cullCacheBytes = numInst * kCacheBytesPerInstance;
-        instances->cullCacheInstVersion = 0;
-    }
-    a.cache = cacheLayout(instances->cullCache, numInst);
-    a.numInstances = (uint32_t)numInst;
-    {
-        const InstanceCullCache c = a.cache;
-        const BasePassInstanceConstants* ip = a.instances;
-        const MeshData* mp = a.meshData;
-        const uint32_t ni = (uint32_t)numInst, nmesh = (uint32_t)numMeshes;
-        ctx.emit("instance_cache", [instances, meshData, c, ip, mp, ni, nmesh](hipStream_t s) {
-            const uint64_t vi = instances->version, vm = meshData->version;      // every earlier write is counted (submission order)
-            if (instances->cullCacheInstVersion == vi && instances->cullCacheMeshVersion == vm && instances->cullCacheMesh == mp) return (int)TRHIP_OK;
-            hipLaunchKernelGGL(instanceCacheKernel, dim3((ni + 255u) / 256u), dim3(256), 0, s, ip, ni, mp, nmesh, c);
-            instances->cullCacheInstVersion = vi; instances->cullCacheMeshVersion = vm; instances->cullCacheMesh = mp;
-            return trhip::launchStatus("instanceCacheKernel"); });
-    }
+    rc = trhip::instanceCacheEnsure(instances);
+    if (rc != TRHIP_OK) return rc;
+    a.cache = instanceCacheLayout(instances->cullCache, instances->byteSize / sizeof(BasePassInstanceConstants));
+    a.numInstances = (uint32_t)(instances->byteSize / sizeof(BasePassInstanceConstants));
+    ctx.emit("instance_cache", [instances, meshData](hipStream_t s) { return trhip::instanceCacheLaunchBuild(instances, meshData, s); });
     a.numBlocks = (nMax + kBlock - 1) / kBlock;
     a.word = (uint32_t*)ctx.scratch((size_t)nMax * 4);
     a.localOff = (uint32_t*)ctx.scratch((size_t)nMax * 4);
@@ -515,7 +478,7 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
     TRHIP_REQUIRE(a.word && a.localOff && a.blockGroups && a.blockLateSubmit && a.bases && a.tileCount && a.tileOf, "%s: scratch allocation failed", ctx.shaderName);
     // sidecar of the amplification buffer: header + one u32 per record slot
     {
-        const uint64_t need = (uint64_t)kPermHeaderWords * 4 + (uint64_t)a.maxGroups * 4;
+        const uint64_t need = (uint64_t)kPermHeaderWords * 4 + (uint64_t)a.maxGroups * 16;
         if (records->sidecarBytes < need) {
             if (records->sidecar) { (void)hipStreamSynchronize(ctx.cl->dev->stream); (void)hipFree(records->sidecar); records->sidecar = nullptr; records->sidecarBytes = 0; }
             void* p = nullptr;
@@ -524,7 +487,7 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
             records->sidecarBytes = need;
         }
         a.permHeader = (uint32_t*)records->sidecar;
-        a.perm = a.permHeader + kPermHeaderWords;
+        a.perm = (uint4*)(a.permHeader + kPermHeaderWords);
         a.permCapacity = a.maxGroups;
     }
     rc = ctx.cl->recordClearWords(a.tileCount, kNumTiles * kTileReplicas, 0);   // joins the pass's other clears in one launch
@@ -569,6 +532,43 @@ trhip::ShaderRegistrar r1("gpuculling_CS_GPUCulling LATE_CULL=1", recordGPUCulli
 trhip::ShaderRegistrar r2("gpuculling_CS_BuildLateCullIndirectArgs", recordBuildLateArgs, 0);
 
 } // namespace
+
+namespace trhip
+{
+
+int instanceCacheEnsure(trhip_buffer_t* instances)
+{
+    const uint64_t n = instances->byteSize / sizeof(BasePassInstanceConstants);
+    TRHIP_REQUIRE(n >= 1 && n <= 0xFFFFFFFFull, "instance cull cache: instance buffer '%s' size out of range", instances->name.c_str());
+    if (instances->cullCacheBytes < n * kInstanceCacheBytesPerInstance) {
+        TRHIP_HIP(hipSetDevice(instances->dev->index));
+        if (instances->cullCache) {
+            int rc = instances->dev->syncAll();
+            if (rc != TRHIP_OK) return rc;
+            (void)hipFree(instances->cullCache);
+            instances->cullCache = nullptr; instances->cullCacheBytes = 0;
+        }
+        TRHIP_HIP(hipMalloc(&instances->cullCache, (size_t)(n * kInstanceCacheBytesPerInstance)));
+        instances->cullCacheBytes = n * kInstanceCacheBytesPerInstance;
+        instances->cullCacheInstVersion = 0;
+    }
+    return TRHIP_OK;
+}
+
+int instanceCacheLaunchBuild(trhip_buffer_t* instances, trhip_buffer_t* meshData, hipStream_t s)
+{
+    const uint64_t vi = instances->version, vm = meshData->version;
+    if (instances->cullCacheInstVersion == vi && instances->cullCacheMeshVersion == vm && instances->cullCacheMesh == meshData->ptr) return TRHIP_OK;
+    const uint32_t n = (uint32_t)(instances->byteSize / sizeof(BasePassInstanceConstants));
+    const uint64_t numMeshes = meshData->byteSize / sizeof(MeshData);
+    hipLaunchKernelGGL(instanceCacheKernel, dim3((n + 255u) / 256u), dim3(256), 0, s, (const BasePassInstanceConstants*)instances->ptr, n,
+                       (const MeshData*)meshData->ptr, (uint32_t)(numMeshes > 0xFFFFFFFFull ? 0xFFFFFFFFull : numMeshes),
+                       instanceCacheLayout(instances->cullCache, n));
+    instances->cullCacheInstVersion = vi; instances->cullCacheMeshVersion = vm; instances->cullCacheMesh = meshData->ptr;
+    return launchStatus("instanceCacheKernel");
+}
+
+} // namespace trhip
 
 extern "C" int trhip_launch_shard_late_info(void* hip_stream, const uint32_t* gathered_counts, uint32_t world, uint32_t rank, uint32_t* info)
 {

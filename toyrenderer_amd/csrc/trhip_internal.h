@@ -232,6 +232,11 @@ int hzbQuadEnsure(trhip_texture_t* tex);
 int hzbQuadEmitBuild(const DispatchCtx& ctx, trhip_texture_t* tex);
 int hzbQuadLaunchBuild(trhip_texture_t* tex, hipStream_t s);
 
+// Instance cull cache (instance_cache.hip.h, k_gpuculling.hip).  ensure: allocate (record time); launch: rebuild on
+// `s` unless it is current -- called while commands are submitted, so every earlier write is counted.
+int instanceCacheEnsure(trhip_buffer_t* instances);
+int instanceCacheLaunchBuild(trhip_buffer_t* instances, trhip_buffer_t* meshData, hipStream_t s);
+
 using RecordFn = int (*)(DispatchCtx&);
 void registerShader(const char* name, RecordFn fn, int variant);
 
