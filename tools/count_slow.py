@@ -1,6 +1,6 @@
 import ctypes as C, os, sys
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from toyrenderer_amd import host, rhi, synth
 import bench
 spec = synth.config_spec(os.environ.get("CFG", "C3"))

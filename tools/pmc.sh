@@ -1,5 +1,5 @@
 #!/bin/bash
-# Usage: bash tools_pmc.sh <tag> <bench flags> -- "<counter group 1>" "<counter group 2>" ...
+# Usage: bash tools/pmc.sh <tag> <bench flags> -- "<counter group 1>" "<counter group 2>" ...
 # One rocprofv3 --pmc pass per group (PMC never combined with sys/hip traces).
 set -e
 TAG=$1; shift

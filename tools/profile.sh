@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profile bench.py on the GPU box: kernel-trace stats + separate PMC passes (never combined with
-# sys/hip traces).  Usage (from repo root, via gpurun):  bash tools_profile.sh <tag> [bench args...]
+# sys/hip traces).  Usage (from repo root, via gpurun):  bash tools/profile.sh <tag> [bench args...]
 set -e
 TAG=${1:-r1}; shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}

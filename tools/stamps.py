@@ -1,7 +1,7 @@
 """Diagnostic: per-segment cycle shares of the meshlet cull kernel (TR_STAMPS build only)."""
 import ctypes as C, os, sys, json, subprocess
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from toyrenderer_amd import host, rhi, synth
 import bench
 spec = synth.config_spec(os.environ.get("CFG", "C3"))

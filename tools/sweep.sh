@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: bash tools_sweep.sh VAR v1 v2 ... -- [bench args]   (prints value, ms/step, cull kernel ms per setting)
+# usage: bash tools/sweep.sh VAR v1 v2 ... -- [bench args]   (prints value, ms/step, cull kernel ms per setting)
 VAR=$1; shift
 VALS=()
 while [ "$1" != "--" ] && [ -n "$1" ]; do VALS+=("$1"); shift; done

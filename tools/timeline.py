@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Print the kernel timeline of the last frames from a rocprofv3 --kernel-trace CSV (start/end relative
-to the frame's first kernel, stream/queue id), to see what overlaps.  usage: tools_timeline.py trace.csv [frames]"""
+to the frame's first kernel, stream/queue id), to see what overlaps.  usage: tools/timeline.py trace.csv [frames]"""
 import csv
 import sys
 

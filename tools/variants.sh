@@ -1,11 +1,11 @@
 #!/bin/bash
 # Build experiment variants of the back end (extra -D flags on k_basepass_as.hip only) into
 # toyrenderer_amd/lib/exp/<name>/libtrhip.so, and (on the GPU box) time each with bench.py.
-#   bash tools_variants.sh build name1 "-DFOO -DBAR" name2 "-DBAZ" ...
-#   bash tools_variants.sh run name1 name2 ... -- [bench args]
+#   bash tools/variants.sh build name1 "-DFOO -DBAR" name2 "-DBAZ" ...
+#   bash tools/variants.sh run name1 name2 ... -- [bench args]
 # Experiment builds are never shipped: lib/exp is git-ignored and deleted after use.
 set -e
-ROOT=$(cd "$(dirname "$0")" && pwd)
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
 CS=$ROOT/toyrenderer_amd/csrc
 LIB=$ROOT/toyrenderer_amd/lib
 MODE=$1; shift

@@ -226,11 +226,6 @@ __device__ __forceinline__ OccSample occlusionPrepare(F3 c, float r, float nearP
     aw = fma_(aw, -0.5f, 0.5f);
     float width = (az - ax) * (float)h.width;                        // :73
     float height = (aw - ay) * (float)h.height;                      // :74
-#ifdef TR_EXPERIMENT_NO_FOOTPRINT      // timing experiment only: skip level / footprint / address math
-    o.i0 = (uint32_t)(width + height); o.i1 = o.i0 & 1023u; o.i0 &= 1023u; o.pair = false;
-    o.depthSphere = div_(nearPlane, c.z - r);
-    return o;
-#endif
     int mip = hzbLevel(width, height, h.mips);                       // :75
     float u = (ax + az) * 0.5f, v = (ay + aw) * 0.5f;                // :78
     // SampleLevel footprint (see sampleHzbMin)
@@ -247,11 +242,7 @@ __device__ __forceinline__ OccSample occlusionPrepare(F3 c, float r, float nearP
     y0 = min(max(y0, 0), ym);
     x1 = wx1 ? x1 : x0;
     y1 = wy1 ? y1 : y0;
-#ifdef TR_EXPERIMENT_NO_MIPLUT
-    uint32_t base = (uint32_t)mip * 64u;
-#else
     uint32_t base = mipOff[mip];
-#endif
     o.i0 = base + (uint32_t)y0 * mw + (uint32_t)x0;
     o.i1 = base + (uint32_t)y1 * mw + (uint32_t)x0;
     o.pair = x1 != x0;                                               // then x1 == x0 + 1

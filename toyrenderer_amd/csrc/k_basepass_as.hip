@@ -12,22 +12,23 @@
 // across groups (the canonical order of SURVEY.md section 7).  LATE_CULL is unused by the
 // reference's AS (Q5), so both permutations are the same kernel.
 //
-// This is the hot kernel of the path: HBM-bound streaming of MeshletData (32 B per meshlet
-// tested, algorithmic).  Structure for CDNA4:
-//   * the unit of work is a BATCH of 64 consecutive records owned by ONE wave64 (no workgroup
-//     barriers anywhere): lane l resolves record l -> instance -> MeshData LOD entry (the three
-//     dependent loads of basepass.hlsl:54-58) once per record, computes the per-record
-//     invariants (max scale, adjugate) and parks them in the wave's private LDS slice;
-//   * main loop, 32 steps: the wave runs two records per step (lanes 0-31 / 32-63); per-record
-//     data are LDS broadcast reads, so the only HBM stream is one 16-B + one 4-B load per lane;
-//     meshlet data are prefetched TWO steps ahead into a two-slot register ring;
-//   * every test is evaluated branch-free and the result is the AND (the tests are pure, so this
-//     equals the reference's short-circuit order :73-108).  That lets the four HZB texel loads be
-//     issued before the next prefetch and before the cone test: vmcnt is in-order, so the texels
-//     can be awaited with the younger prefetch still in flight, and their latency hides under the
-//     cone test's ALU work;
-//   * the 64-bit ballot is the two groups' visibility masks (WaveActiveCountBits/WavePrefix-
-//     CountBits :116-120); masks and the batch popcount are written once per batch.
+// This is the hot kernel of the path (32 B of MeshletData per meshlet tested).  Structure for
+// CDNA4 (DESIGN.md section 5 has the measurements behind each point):
+//   * the unit of work is a BATCH of 64 records owned by ONE wave64 (no workgroup barriers in the loop): lane l
+//     resolves its record through the instance cull cache (instance_cache.hip.h; the record itself comes from the
+//     permuted copy the instance pass wrote and is fetched while the previous batch runs), computes the adjugate
+//     and parks 96 B of per-record invariants in the wave's private LDS slice, (x, y) pairs first;
+//   * main loop, <= 32 steps: two records per step (lanes 0-31 / 32-63); per-record data are LDS broadcast
+//     reads; the meshlet stream is two coalesced, non-temporal 16-B loads per lane prefetched TWO steps ahead into
+//     a two-slot register ring that is pinned as 128-bit tuples, so every wait in the loop is partial;
+//   * every test is evaluated branch-free and the result is the AND (the tests are pure, so this equals the
+//     reference's short-circuit order :73-108); the x / y halves of the projection, the 3x3 products and the cone
+//     decode run as packed fp32 pairs (same IEEE operation per component);
+//   * the HZB lookup is ONE 2-byte load from the footprint-min table (k_hzb.hip), issued before the prefetch and
+//     first used after the cone test; the rare lookups the table cannot serve are deferred to the texel path and
+//     patched into the batch's masks while those are still in LDS;
+//   * the loop issues no stores: the 64 masks of a batch (WaveActiveCountBits/WavePrefixCountBits :116-120 as
+//     ballots) are staged in LDS and leave in one store.
 #include <algorithm>
 #include <cstdlib>
 #include <string>
@@ -72,8 +73,6 @@ __device__ __forceinline__ cm::M33P adjugateOf(const RecordInfo& ri)
 struct MeshletCullArgs
 {
     BasePassConstants k;
-    const BasePassInstanceConstants* instances;
-    const MeshData* meshData;
     const MeshletData* meshlets;
     const MeshletAmplificationData* records;
     cm::Hzb hzb;
@@ -744,8 +743,6 @@ int recordASMain(trhip::DispatchCtx& ctx)
         }
     }
     if (rc != TRHIP_OK) return rc;
-    a.instances = (const BasePassInstanceConstants*)instances->ptr;
-    a.meshData = (const MeshData*)meshData->ptr;
     a.meshlets = (const MeshletData*)meshlets->ptr;
     a.records = (const MeshletAmplificationData*)records->ptr;
     a.dispatchArgs = (const uint32_t*)((const char*)ctx.argsBuffer->ptr + ctx.argsOffset);
