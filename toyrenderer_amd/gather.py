@@ -202,6 +202,9 @@ class HipShardExchange(ShardExchange):
 
         # in-frame exchange of the late-list lengths (module docstring)
         self.late_counts = [torch.zeros(self.world, dtype=torch.int32, device="cuda") for _ in range(2)]
+        # its own communicator: the 4-byte in-frame collective must not queue behind the previous frame's slot
+        # exchange on the process group's stream (every rank creates the group, in the same order)
+        self.late_group = dist.new_group()
         self._ptr_views = {}
         self._hook_error = None
         renderer.set_shard_late_exchange(self.late_exchange)
@@ -213,7 +216,7 @@ class HipShardExchange(ShardExchange):
             if t is None:
                 t = self._ptr_views[late_count_ptr] = self.torch.as_tensor(_DevWords(late_count_ptr, 1), device="cuda")
             with self.torch.cuda.stream(self.compute):
-                self.dist.all_gather_into_tensor(self.late_counts[bucket], t)
+                self.dist.all_gather_into_tensor(self.late_counts[bucket], t, group=self.late_group)
             rc = self.rhi.load().trhip_launch_shard_late_info(hip_stream, self.late_counts[bucket].data_ptr(), self.world, self.rank, shard_info_ptr)
             if rc != 0:
                 raise RuntimeError(self.rhi.load().trhip_last_error().decode(errors="replace"))
