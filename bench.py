@@ -180,6 +180,7 @@ def main():
                                   group_capacity=spec.num_instances * groups_per_instance,
                                   overlap=not os.environ.get("TR_NO_OVERLAP"))
 
+    rec_hist = []
     cpu_t = [0.0, 0.0, 0.0, 0.0]                          # host time spent submitting: frame, exchange (diagnostics, stderr only)
 
     def step():
@@ -190,6 +191,7 @@ def main():
         rec_ms, sub_ms = r.renderer_times("<frame>")
         cpu_t[2] += rec_ms
         cpu_t[3] += sub_ms
+        rec_hist.append(rec_ms)
         if gather:
             gather.run()
         cpu_t[0] += t_b - t_a
@@ -211,6 +213,8 @@ def main():
     t_submit = time.perf_counter() - t0
     sync()
     dt = time.perf_counter() - t0
+    log(f"[rank {rank}] record ms per frame, first 12 timed frames: " + " ".join(f"{x:.3f}" for x in rec_hist[-args.steps:][:12])
+        + " ... last 4: " + " ".join(f"{x:.3f}" for x in rec_hist[-4:]))
     log(f"[rank {rank}] host submission per step: frame {cpu_t[0] / args.steps * 1e3:.3f} ms (record {cpu_t[2] / args.steps:.3f}, submit {cpu_t[3] / args.steps:.3f}), exchange {cpu_t[1] / args.steps * 1e3:.3f} ms; "
         f"all steps submitted after {t_submit * 1e3:.2f} ms of {dt * 1e3:.2f} ms")
     if dist is not None:

@@ -163,3 +163,37 @@ def test_bench_rccl_gather_path_single_rank():
     assert out["gather_checked"] is True
     assert out["value"] > 0 and out["roofline"]["achieved"] > 0 and out["cpu_baseline"]["value"] > 0
     assert out["config"]["meshlets_tested_per_frame"] > 100_000
+
+
+@pytest.mark.parametrize("flags", [5, 7])
+def test_cornell_scene_through_the_drop_in_path(oracle, flags):
+    """BASELINE.json configs[0] on the GPU: the scene derived from the reference's cornell.gltf (fixture
+    tests/golden/cornell_scene.npz, tests/golden/make_cornell.py) -- node transforms -> world matrices on the GPU
+    (UpdateInstanceConstsRenderer), then the cull; outputs equal the fixture's (= the oracle's) bit for bit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gltf_cornell import _cull, _fixture
+    from toyrenderer_amd import gltf_lite
+    z, scene, camera = _fixture()
+    view = gltf_lite.view_of(camera, (1920, 1080))
+    with _Ctx((1920, 1080)) as r:
+        r.load_scene(scene.instances, scene.meshData, scene.meshlets, scene.opaqueIds, scene.alphaMaskIds)
+        r.load_nodes(scene.nodes, scene.primToNode)
+        r.set_culling(flags)
+        if flags & 2:
+            r.upload_depth(np.zeros((1080, 1920), np.float32))
+        for frame in range(2):
+            r.set_node_transforms(scene.nodes)
+            r.set_camera(view)
+            r.frame()
+        got = r.results()
+        assert np.array_equal(r.instances(3)["m_WorldMatrix"], z[f"world_{flags}"])
+    inst, ref = _cull(oracle, scene, view, flags)
+    for s in (0, 1):
+        if f"f{flags}_s{s}_records" not in z.files:
+            continue
+        assert np.array_equal(got[s]["records"].view(np.uint32).reshape(-1, 3), z[f"f{flags}_s{s}_records"]), f"slot {s}: records"
+        assert np.array_equal(got[s]["visMask"], z[f"f{flags}_s{s}_visMask"]), f"slot {s}: masks"
+        assert np.array_equal(got[s]["visibleList"], z[f"f{flags}_s{s}_visibleList"]), f"slot {s}: visible list"
+    assert int(got[0]["drawArgs"][0]) == int(ref.drawArgs[0][0]) >= 3
