@@ -355,3 +355,17 @@ def test_zero_weight_hzb_lookups_take_the_texel_path(dev, oracle):
     finally:
         drv.release()
         gs.release()
+
+
+@pytest.mark.parametrize("render,flags", [((640, 360), 7), ((300, 1000), 7), ((100, 100), 3), ((640, 360), 6)])
+def test_table_kernel_on_small_and_non_square_hzbs(dev, oracle, render, flags):
+    """The footprint-min-table variant of the early meshlet cull (chosen for record capacities >= 2^19, otherwise only
+    reached by the full-size configs) on non-square and tiny HZBs (512x256, 256x512, 64x64: top mips 1 texel wide),
+    two frames with HZB feedback, and with 6000 instances so that the tile-sorted processing order is on as well."""
+    view = synth.make_view(eye=(0.5, 0.2, 1.0), yaw=0.03, prev_eye=(0.0, 0.0, 0.0), prev_yaw=0.0, render=render)
+    d_prev = synth.gen_depth(view, num_occluders=60, seed=11, scale=3.0)
+    d_cur = synth.gen_depth(view, num_occluders=40, seed=12, scale=3.0)
+    spec = synth.SceneSpec(num_meshes=40, num_instances=6000, meshlets_lod0=70, jitter_meshlets=True, max_lods=4,
+                           alpha_mask_fraction=0.1, seed=77)
+    got, ref = _run_case(dev, oracle, spec, view, flags=flags, max_groups=1 << 19, depth_prev=d_prev, depth_cur=d_cur, frames=2)
+    assert ref.dispatchArgs[0][0] > 1000 and 0 < ref.drawArgs[0][0] < ref.meshletsTested[0]
