@@ -36,6 +36,28 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f splat2(float x) { return v2f{ x, x }; }
 
+// Correctly rounded square roots of two values.  For x in [2^-96, FLT_MAX] the 8-operation sequence below
+// (v_rsq_f32, one coupled Newton step on (sqrt, 1/(2 sqrt)), one residual correction; 6 of the 8 packed) returns
+// exactly the IEEE result -- verified EXHAUSTIVELY on gfx950 against the compiler's expansion for all 1 879 048 192
+// floats of that range (tools/sqrt_exhaustive.hip; below 2^-96 it does not hold, which is why the compiler's 16-
+// operation expansion rescales).  Anything outside the range anywhere in the wave (zero, tiny, negative, inf, NaN)
+// sends the whole wave through the compiler's sqrt.
+__device__ __forceinline__ v2f sqrt2(v2f x)
+{
+#ifdef TR_EXPERIMENT_FAST_MATH
+    return v2f{ __builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y) };
+#else
+    const bool inRange = (int)((__float_as_uint(x.x) - 0x0F800000u) < 0x70000000u) & (int)((__float_as_uint(x.y) - 0x0F800000u) < 0x70000000u);
+    if (__builtin_expect(__ballot(!inRange) != 0ull, 0)) return v2f{ __builtin_sqrtf(x.x), __builtin_sqrtf(x.y) };
+    const v2f y = { __builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y) };
+    const v2f g0 = x * y, h0 = y * splat2(0.5f);
+    const v2f r0 = fma2(-h0, g0, splat2(0.5f));
+    const v2f g1 = fma2(g0, r0, g0), h1 = fma2(h0, r0, h0);
+    const v2f d1 = fma2(-g1, g1, x);
+    return fma2(d1, h1, g1);
+#endif
+}
+
 // Correctly rounded a / b per component (== the compiler's IEEE fdiv expansion: v_div_scale, v_rcp, Newton steps,
 // v_div_fmas, v_div_fixup) with the six fma / mul steps of the two divisions issued as packed instructions.
 __device__ __forceinline__ v2f div2(v2f n, v2f d)
@@ -290,7 +312,7 @@ __device__ __forceinline__ OccQuad occlusionPrepareQuad(F3 c, float r, float nea
     const float crz = c.z * r;                                       // :53 cr.z
     const float czr2 = fma_(c.z, c.z, -(r * r));                     // :54
     const v2f vArg = fma2(cxy, cxy, splat2(czr2));
-    const v2f vv = { sqrt_(vArg.x), sqrt_(vArg.y) };                 // :56, :60  vx, vy
+    const v2f vv = sqrt2(vArg);                                      // :56, :60  vx, vy
     const v2f czz = splat2(c.z);
     const v2f mn = div2(fma2(vv, cxy, splat2(-crz)), fma2(vv, czz, cr));    // :57, :61  minx, miny
     const v2f mx = div2(fma2(vv, cxy, splat2(crz)), fma2(vv, czz, -cr));    // :58, :62  maxx, maxy
@@ -367,12 +389,13 @@ __device__ __forceinline__ bool coneBackfacingP(uint32_t packed, F3 cv, float r,
     const v2f a01 = fma2(q01, splat2(2.0f), splat2(-1.0f));
     const F3 a = { a01.x, a01.y, fma_(q23.x, 2.0f, -1.0f) };
     F3 t = mulVecP(a, adj);
-    const float len = sqrt_(dot3(t, t));
+    const v2f lens = sqrt2(v2f{ dot3(t, t), dot3(cv, cv) });                       // length(t), length(cv)
+    const float len = lens.x;
     const v2f txy = div2(v2f{ t.x, t.y }, splat2(len));                            // normalize = v / length
     t = { txy.x, txy.y, div_(t.z, len) };
     F3 axis = mulVecP(t, viewRot);
     axis.z = -axis.z;
-    return dot3(cv, axis) >= fma_(q23.y, sqrt_(dot3(cv, cv)), r);
+    return dot3(cv, axis) >= fma_(q23.y, lens.y, r);
 }
 
 __device__ __forceinline__ M43 loadM43(const interop::Matrix& m)
