@@ -301,6 +301,9 @@ struct OccQuad
     uint32_t iq;              // table index (always in range: uv is clamped to [0,1] and NaN-free)
 };
 
+// DEPTH: also compute depthSphere = nearPlane / (c.z - r) here (:79); otherwise the caller pairs that division with
+// another one (coneBackfacingP) and fills the field itself.
+template <bool DEPTH = true>
 __device__ __forceinline__ OccQuad occlusionPrepareQuad(F3 c, float r, float nearPlane, float P00, float P11, const Hzb& h,
                                                         const uint32_t* quadOff, uint32_t quadTotal)
 {
@@ -339,7 +342,7 @@ __device__ __forceinline__ OccQuad occlusionPrepareQuad(F3 c, float r, float nea
     o.slow = slowX | slowY;
     uint32_t iq = quadOff[mip] + (uint32_t)(y0 + 1) * (mw + 1u) + (uint32_t)(x0 + 1);
     o.iq = iq < quadTotal ? iq : quadTotal - 1u;
-    o.depthSphere = div_(nearPlane, c.z - r);                        // :79
+    o.depthSphere = DEPTH ? div_(nearPlane, c.z - r) : 0.0f;         // :79
     return o;
 }
 
@@ -377,8 +380,11 @@ __device__ __forceinline__ bool coneBackfacing(uint32_t packed, F3 cv, float r, 
     return dot3(cv, axis) >= fma_(cutoff, sqrt_(dot3(cv, cv)), r);
 }
 
-// == coneBackfacing, with the byte decode, the two 3x3 products and two of the three normalisation divisions packed
-__device__ __forceinline__ bool coneBackfacingP(uint32_t packed, F3 cv, float r, const M33P& adj, const M33P& viewRot)
+// == coneBackfacing, with the byte decode, the two 3x3 products and the normalisation divisions packed.  The third
+// normalisation division shares its instruction slots with one unrelated division of the caller: extraQuotient =
+// extraNum / extraDen (the occlusion test's nearPlane / (c.z - r), culling.hlsli:79).
+__device__ __forceinline__ bool coneBackfacingP(uint32_t packed, F3 cv, float r, const M33P& adj, const M33P& viewRot,
+                                                float extraNum, float extraDen, float* extraQuotient)
 {
     const float rc = 0x1.010102p-8f;         // RN(1/255), see u8Unorm
     const v2f x01 = { (float)(packed & 0xFFu), (float)((packed >> 8) & 0xFFu) };
@@ -392,7 +398,9 @@ __device__ __forceinline__ bool coneBackfacingP(uint32_t packed, F3 cv, float r,
     const v2f lens = sqrt2(v2f{ dot3(t, t), dot3(cv, cv) });                       // length(t), length(cv)
     const float len = lens.x;
     const v2f txy = div2(v2f{ t.x, t.y }, splat2(len));                            // normalize = v / length
-    t = { txy.x, txy.y, div_(t.z, len) };
+    const v2f tzq = div2(v2f{ t.z, extraNum }, v2f{ len, extraDen });
+    *extraQuotient = tzq.y;
+    t = { txy.x, txy.y, tzq.x };
     F3 axis = mulVecP(t, viewRot);
     axis.z = -axis.z;
     return dot3(cv, axis) >= fma_(q23.y, lens.y, r);

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
             cm::OccSample os;
             uint32_t footprintBits = 0, row0 = 0, row1 = 0;
             if (OCCLUSION && TABLE) {                                                              // :75-88 (Q4)
-                oq = cm::occlusionPrepareQuad(cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_quadOff, a.quad.total);
+                oq = cm::occlusionPrepareQuad<!CONE>(cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_quadOff, a.quad.total);
                 footprintBits = reinterpret_cast<const uint16_t*>(a.quad.base)[oq.iq];             // the one 2-byte load of the lookup
             }
             if (OCCLUSION && !TABLE) {
@@ -318,7 +318,11 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
                 slot = loadMeshletChunks(a.meshlets, s_rec[rn].meshletBase, s_rec[rn].count, sub);
             }
             if (CONE)                                                                              // :90-108
-                vis &= !cm::coneBackfacingP(cone, cv, rad, adjugateOf(ri), VR);
+            {
+                float q = 0.0f;                                                                    // :79 rides along with the cone's divisions
+                vis &= !cm::coneBackfacingP(cone, cv, rad, adjugateOf(ri), VR, a.k.m_NearPlane, cv.z - rad, &q);
+                if (OCCLUSION && TABLE) oq.depthSphere = q;
+            }
             TR_STAMP(4);   // prefetch issue + cone
             if (OCCLUSION && !TABLE)
                 vis &= cm::occlusionResolve(os, row0, row1);
@@ -384,7 +388,8 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
                     bool vis = true;
                     if (FRUSTUM) vis &= cm::frustumVisible(cv, rad, a.k.m_Frustum.x, a.k.m_Frustum.y, a.k.m_Frustum.z, a.k.m_Frustum.w);
                     vis &= cm::occlusionVisible(cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb);
-                    if (CONE) vis &= !cm::coneBackfacingP(cone, cv, rad, adjugateOf(ri), VR);
+                    float unused;
+                    if (CONE) vis &= !cm::coneBackfacingP(cone, cv, rad, adjugateOf(ri), VR, 1.0f, 1.0f, &unused);
                     return vis;
                 };
                 if (nSlow <= kSlowCap) {                                             // patch single bits
