@@ -90,3 +90,17 @@ def test_c3_bench_workload_100m_meshlets(oracle):
     assert int(ref.meshletsTested[0]) > 50_000_000 and 0 < int(ref.drawArgs[0][0]) < int(ref.meshletsTested[0])
     for s in (0, 1):
         _properties(got, s)
+
+
+def test_c2_without_the_side_stream():
+    """The same C2 frames with the back end's side stream switched off (TRHIP_NO_SIDE_STREAM=1: list build and
+    footprint-table rebuild run in order on the main stream) -- the overlap machinery must not be what makes
+    the results right."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TRHIP_NO_SIDE_STREAM="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_full_size.py"), "-q", "-x", "-k", "c2_instanced"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0 and "1 passed" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
