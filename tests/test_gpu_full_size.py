@@ -104,3 +104,56 @@ def test_c2_without_the_side_stream():
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_full_size.py"), "-q", "-x", "-k", "c2_instanced"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert p.returncode == 0 and "1 passed" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_c4_rank_share_animated_transforms(oracle):
+    """configs[4] "Synthetic 1B meshlets with per-frame animated instance transforms, 8 GPUs": ONE rank's share
+    (976 562 instances x 128 unique meshlets = 125 M meshlets, 4 GB) on this GPU.  Every frame the node transforms
+    change (a two-level hierarchy: 4096 group nodes above the instance nodes), UpdateInstanceConstsRenderer rewrites
+    the world matrices on the GPU, the instance cull cache follows, then the full 2-phase cull runs; world matrices
+    and all outputs equal the oracle's."""
+    from toyrenderer_amd import host, interop as I
+    spec = synth.config_spec("C4r")
+    view = synth.make_view(eye=(0.0, 0.0, 0.0), prev_eye=(0.05, 0.0, 0.1), prev_yaw=0.002)
+    scene = synth.make_scene(spec)
+    depth = synth.gen_depth(view, 200)
+    hzb = oracle.HzbTexture(*view.hzb_dims)
+    n, groups = spec.num_instances, 4096
+    cap = n * 4 + 1
+    rng = np.random.default_rng(44)
+    nodes = np.zeros(n + groups, I.NodeLocalTransform)
+    nodes["m_ParentNodeIdx"][:n] = n + rng.integers(0, groups, n)
+    nodes["m_ParentNodeIdx"][n:] = 0xFFFFFFFF
+    prim_to_node = np.arange(n, dtype=np.uint32)
+    r = host.Renderer(render=(view.renderW, view.renderH), max_groups=cap, max_transient_bytes=8 << 30)
+    try:
+        r.load_scene(scene.instances, scene.meshData, scene.meshlets, scene.opaqueIds, scene.alphaMaskIds)
+        r.load_nodes(nodes, prim_to_node)
+        r.set_culling(7)
+        r.upload_depth(depth)
+        inst = scene.instances.copy()
+        for frame in range(2):
+            q = rng.standard_normal((n + groups, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+            nodes["m_Rotation"] = q.astype(np.float32)
+            nodes["m_Scale"][:n] = rng.uniform(0.5, 2.0, (n, 1)).astype(np.float32)
+            nodes["m_Scale"][n:] = 1.0
+            nodes["m_Position"][:n] = rng.standard_normal((n, 3)).astype(np.float32) * 3.0
+            gp = np.empty((groups, 3), np.float32)
+            gp[:, 0] = rng.uniform(-spec.box_x, spec.box_x, groups); gp[:, 1] = rng.uniform(-spec.box_y, spec.box_y, groups)
+            gp[:, 2] = -rng.uniform(spec.z_near, spec.z_far, groups)
+            nodes["m_Position"][n:] = gp
+            r.set_node_transforms(nodes)
+            r.set_camera(view)
+            r.frame()
+            oracle.update_instance_consts(nodes, prim_to_node, inst)
+            got_inst = r.instances(n)
+            assert np.array_equal(got_inst["m_WorldMatrix"], inst["m_WorldMatrix"]), f"frame {frame}: world matrices"
+            sc = dict(scene.as_oracle()); sc["instances"] = inst
+            ref = oracle.frame(sc, view.as_dict(), hzb, depth, cullingFlags=7, maxGroups=cap, record_capacity=cap, threads=16)
+            got = r.results()
+            _compare(got, ref)
+        assert int(ref.meshletsTested[0]) > 10_000_000 and int(ref.lateCount[0]) > 64
+        for s in (0, 1):
+            _properties(got, s)
+    finally:
+        r.shutdown()

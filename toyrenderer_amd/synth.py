@@ -262,6 +262,8 @@ def config_spec(name: str) -> SceneSpec:
                          alpha_mask_fraction=0.1)
     if name == "C3":   # 100 M unique meshlets, 781 250 x 128, one LOD (tested count exact)
         return SceneSpec(num_meshes=781_250, num_instances=781_250, meshlets_lod0=128, max_lods=1, unique=True)
+    if name == "C4r":  # one rank's share of C4 (1 B meshlets over 8 GPUs): 125 M unique meshlets; transforms animated by the caller
+        return SceneSpec(num_meshes=976_562, num_instances=976_562, meshlets_lod0=128, max_lods=1, unique=True)
     if name == "C3e":  # 1/8 of C3: the per-GPU share of the 8-GPU run (overhead proxy on one GPU)
         return SceneSpec(num_meshes=97_656, num_instances=97_656, meshlets_lod0=128, max_lods=1, unique=True)
     if name == "C3s":  # 1/64 of C3 for quick GPU parity runs
