@@ -72,15 +72,18 @@ int  trhost_pass_buffers(uint32_t slot, trhost_pass_buffers_t* out);
 int  trhost_instance_buffer(void** buffer);
 void* trhost_device(void);     /* the trhip_device in use                                           */
 
-/* Multi-GPU (one process per GPU, instance list sharded; not in the reference).  When set, the late
- * instance cull of every bucket (0 opaque, 1 alpha mask) is preceded by fn(user, hip_stream,
- * late_count, shard_info, bucket), called on the thread inside trhost_frame while the frame is
- * submitted: late_count is the device address of this rank's late-list length (1 x u32, final at that
- * point of the stream), shard_info the device address of 2 x u32 that fn must fill -- by work enqueued
- * on hip_stream -- with {late entries of the lower ranks, late entries of all ranks}
- * (an all-gather of late_count + trhip_launch_shard_late_info).  The late dispatch then covers exactly
- * the entries the single-GPU dispatch would (gpuculling.hlsl:182-195).  fn = NULL removes the hook. */
-typedef void (*trhost_shard_late_fn)(void* user, void* hip_stream, void* late_count, void* shard_info, int bucket);
+/* Multi-GPU (one process per GPU, instance list sharded; not in the reference).  When set, fn(user, hip_stream,
+ * late_count, shard_info, bucket, phase) is called on the thread inside trhost_frame while the frame is submitted,
+ * twice per bucket (0 opaque, 1 alpha mask):
+ *   phase 0  right after the EARLY instance cull: late_count (device address of this rank's late-list length, 1 x u32)
+ *            is final from this point of hip_stream on.  Start the exchange -- typically on another stream, after an
+ *            event recorded on hip_stream: all-gather late_count, then trhip_launch_shard_late_info fills shard_info
+ *            (2 x u32) with {late entries of the lower ranks, late entries of all ranks}.  It has the whole early
+ *            meshlet cull and the HZB build to complete.
+ *   phase 1  right before the LATE instance cull: make hip_stream wait for shard_info (event wait).
+ * The late dispatch then covers exactly the entries the single-GPU dispatch would (gpuculling.hlsl:182-195).
+ * fn = NULL removes the hook. */
+typedef void (*trhost_shard_late_fn)(void* user, void* hip_stream, void* late_count, void* shard_info, int bucket, int phase);
 int  trhost_set_shard_late_exchange(trhost_shard_late_fn fn, void* user);
 
 int  trhost_render_graph_stats(uint32_t* num_heaps, uint64_t* bytes_reserved, uint64_t* bytes_used, uint32_t* num_passes);

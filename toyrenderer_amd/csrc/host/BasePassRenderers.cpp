@@ -37,10 +37,28 @@ struct { ShardLateFn fn = nullptr; void* user = nullptr; } g_ShardLateExchange;
 struct ShardLateCall { nvrhi::BufferHandle info; void* lateCount = nullptr; void* infoPtr = nullptr; int bucket = 0; };
 ShardLateCall g_ShardLateCalls[2];                                           // opaque, alpha mask
 
+template <int PHASE>
 void ShardLateTrampoline(void* user, void* hipStream)
 {
     const ShardLateCall* c = (const ShardLateCall*)user;
-    if (g_ShardLateExchange.fn) g_ShardLateExchange.fn(g_ShardLateExchange.user, hipStream, c->lateCount, c->infoPtr, c->bucket);
+    if (g_ShardLateExchange.fn) g_ShardLateExchange.fn(g_ShardLateExchange.user, hipStream, c->lateCount, c->infoPtr, c->bucket, PHASE);
+}
+
+ShardLateCall& PrepareShardLateCall(bool bAlphaMaskPrimitives, nvrhi::IBuffer* lateCullInstanceCountBuffer)
+{
+    ShardLateCall& call = g_ShardLateCalls[bAlphaMaskPrimitives ? 1 : 0];
+    if (!call.info) {
+        nvrhi::BufferDesc desc;
+        desc.byteSize = 2 * sizeof(uint32_t);
+        desc.structStride = sizeof(uint32_t);
+        desc.canHaveUAVs = true;
+        desc.debugName = bAlphaMaskPrimitives ? "ShardLateInfoAlphaMask" : "ShardLateInfoOpaque";
+        call.info = g_Graphic.m_NVRHIDevice->createBuffer(desc);
+    }
+    call.lateCount = trhip_buffer_device_ptr(lateCullInstanceCountBuffer->native());
+    call.infoPtr = trhip_buffer_device_ptr(call.info->native());
+    call.bucket = bAlphaMaskPrimitives ? 1 : 0;
+    return call;
 }
 }
 
@@ -298,23 +316,16 @@ public:
                 computePassParams.m_BindingSetDesc = bindingSetDesc;
                 computePassParams.m_DispatchGroupSize = Vector3U{ 1, 1, 1 };
                 g_Graphic.AddComputePass(computePassParams);
+                // multi-GPU: the late-list length is final from here on -- the exchange starts now and has the whole
+                // early meshlet cull to complete (trhost.h)
+                if (g_ShardLateExchange.fn)
+                    commandList->hostCallback(&ShardLateTrampoline<0>, &PrepareShardLateCall(bAlphaMaskPrimitives, lateCullInstanceCountBuffer.Get()));
             }
         } else if (m_bDoOcclusionCulling) {                                   // :392-402
             if (g_ShardLateExchange.fn) {
                 // multi-GPU: the late dispatch size rule sees the whole scene's late list (trhost.h)
-                ShardLateCall& call = g_ShardLateCalls[bAlphaMaskPrimitives ? 1 : 0];
-                if (!call.info) {
-                    nvrhi::BufferDesc desc;
-                    desc.byteSize = 2 * sizeof(uint32_t);
-                    desc.structStride = sizeof(uint32_t);
-                    desc.canHaveUAVs = true;
-                    desc.debugName = bAlphaMaskPrimitives ? "ShardLateInfoAlphaMask" : "ShardLateInfoOpaque";
-                    call.info = g_Graphic.m_NVRHIDevice->createBuffer(desc);
-                }
-                call.lateCount = trhip_buffer_device_ptr(lateCullInstanceCountBuffer->native());
-                call.infoPtr = trhip_buffer_device_ptr(call.info->native());
-                call.bucket = bAlphaMaskPrimitives ? 1 : 0;
-                commandList->hostCallback(&ShardLateTrampoline, &call);
+                ShardLateCall& call = PrepareShardLateCall(bAlphaMaskPrimitives, lateCullInstanceCountBuffer.Get());
+                commandList->hostCallback(&ShardLateTrampoline<1>, &call);
                 bindingSetDesc.bindings.push_back(nvrhi::BindingSetItem::StructuredBuffer_SRV(4, call.info));
             }
             Graphic::ComputePassParams computePassParams;

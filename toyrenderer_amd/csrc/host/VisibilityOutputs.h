@@ -21,6 +21,6 @@ bool GetVisibilityPassBuffers(uint32_t slot, VisibilityPassBuffers* out);
 void ReleaseVisibilityPassBuffers();
 
 // Multi-GPU (instance list sharded over ranks; trhost.h trhost_set_shard_late_exchange): called while
-// the frame is submitted, before each late instance cull.
-using ShardLateFn = void (*)(void* user, void* hipStream, void* lateCount, void* shardInfo, int bucket);
+// the frame is submitted: after each early instance cull (phase 0) and before each late one (phase 1).
+using ShardLateFn = void (*)(void* user, void* hipStream, void* lateCount, void* shardInfo, int bucket, int phase);
 void SetShardLateExchange(ShardLateFn fn, void* user);

@@ -61,8 +61,8 @@ class FrameDriver:
                  shard_late=None):
         """alloc(nbytes, name, stride, indirect) -> rhi.Buffer or None: lets the caller own the memory of the
         output buffers (e.g. torch tensors handed to RCCL, gather.py); None -> device allocation.
-        shard_late(hip_stream, late_count_ptr, shard_info_ptr, bucket): multi-GPU hook, called while the
-        frame is submitted, before each late instance cull (same contract as include/trhost.h)."""
+        shard_late(hip_stream, late_count_ptr, shard_info_ptr, bucket, phase): multi-GPU hook, called while the
+        frame is submitted: phase 0 after each early instance cull, phase 1 before each late one (include/trhost.h)."""
         self.shard_late = shard_late
         self.shardInfo = [dev.create_buffer(8, f"ShardLateInfo{b}") for b in (0, 1)] if shard_late is not None else None
         self.dev, self.scene, self.view = dev, scene, view
@@ -159,11 +159,14 @@ class FrameDriver:
             cl.dispatch(name, bindings, ((nb + 31) // 32, 1, 1))                          # :367-375
             if occ:                                                                       # :377-389
                 cl.dispatch("gpuculling_CS_BuildLateCullIndirectArgs", [SRV(0, late_count), UAV(0, late_args)], (1, 1, 1))
+                if self.shard_late is not None:                                           # multi-GPU only (trhost.h)
+                    b = int(alpha_mask)
+                    cl.host_callback(lambda stream, c=late_count.ptr, i=self.shardInfo[b].ptr, b=b: self.shard_late(stream, c, i, b, 0))
         elif occ:
             if self.shard_late is not None:                                               # multi-GPU only (trhost.h)
                 bucket = int(alpha_mask)
                 info = self.shardInfo[bucket]
-                cl.host_callback(lambda stream, c=late_count.ptr, i=info.ptr, b=bucket: self.shard_late(stream, c, i, b))
+                cl.host_callback(lambda stream, c=late_count.ptr, i=info.ptr, b=bucket: self.shard_late(stream, c, i, b, 1))
                 bindings.append(SRV(4, info))
             cl.dispatch_indirect(name, bindings, late_args)                               # :392-402
         else:

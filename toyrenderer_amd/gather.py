@@ -20,10 +20,12 @@ next frame's culling (send/receive buffers are double-buffered and guarded by ev
 One more, tiny, collective sits INSIDE the frame: the reference sizes the late instance cull from the
 late-list length (gpuculling.hlsl:182-195: ceil(count/64) groups of 32 threads, i.e. only the first
 ceil(count/64)*32 entries are processed).  For the sharded run to equal the single-GPU run that rule must
-see the whole scene's late list, so before each late instance cull the ranks all-gather their late
-counts (4 bytes each, device to device, no host read-back) and a one-thread kernel derives {entries of
-the lower ranks, entries of all ranks} for the late dispatch (`late_exchange`, hooked into the frame
-through trhost_set_shard_late_exchange / FrameDriver(shard_late=...)).
+see the whole scene's late list, so the ranks all-gather their late counts (4 bytes each, device to
+device, no host read-back) and a one-thread kernel derives {entries of the lower ranks, entries of all
+ranks} for the late dispatch.  The late count is final right after the EARLY instance cull, so the
+exchange is posted there, on an auxiliary stream, and has the whole early meshlet cull and HZB build to
+complete; the compute stream only waits for its event before the late instance cull (`late_exchange`,
+hooked into the frame through trhost_set_shard_late_exchange / FrameDriver(shard_late=...)).
 Group-capacity overflow (the reference's 65 535-group cap, Q2) is NOT made global: a sharded run equals
 the single-GPU run only if no rank drops groups; a rank that does raises STATUS_GROUPS_DROPPED.
 torch.distributed is plumbing here (process group + the RCCL calls).
@@ -205,21 +207,33 @@ class HipShardExchange(ShardExchange):
         # its own communicator: the 4-byte in-frame collective must not queue behind the previous frame's slot
         # exchange on the process group's stream (every rank creates the group, in the same order)
         self.late_group = dist.new_group()
+        self.aux = torch.cuda.Stream()
+        self.late_posted = [torch.cuda.Event() for _ in range(2)]
+        self.late_ready = [torch.cuda.Event() for _ in range(2)]
         self._ptr_views = {}
         self._hook_error = None
         renderer.set_shard_late_exchange(self.late_exchange)
 
-    def late_exchange(self, hip_stream: int, late_count_ptr: int, shard_info_ptr: int, bucket: int):
-        """Runs inside renderer.frame(), on the compute stream, before a late instance cull."""
+    def late_exchange(self, hip_stream: int, late_count_ptr: int, shard_info_ptr: int, bucket: int, phase: int):
+        """Runs inside renderer.frame() (include/trhost.h).  Phase 0, right after the early instance cull: the
+        all-gather of the late counts and the {lower ranks, all ranks} kernel go to the auxiliary stream, behind an
+        event on the compute stream -- they complete while the early meshlet cull runs.  Phase 1, right before the late
+        instance cull: the compute stream waits for that result."""
         try:
+            if phase == 1:
+                self.compute.wait_event(self.late_ready[bucket])
+                return
             t = self._ptr_views.get(late_count_ptr)
             if t is None:
                 t = self._ptr_views[late_count_ptr] = self.torch.as_tensor(_DevWords(late_count_ptr, 1), device="cuda")
-            with self.torch.cuda.stream(self.compute):
+            self.late_posted[bucket].record(self.compute)
+            with self.torch.cuda.stream(self.aux):
+                self.aux.wait_event(self.late_posted[bucket])
                 self.dist.all_gather_into_tensor(self.late_counts[bucket], t, group=self.late_group)
-            rc = self.rhi.load().trhip_launch_shard_late_info(hip_stream, self.late_counts[bucket].data_ptr(), self.world, self.rank, shard_info_ptr)
-            if rc != 0:
-                raise RuntimeError(self.rhi.load().trhip_last_error().decode(errors="replace"))
+                rc = self.rhi.load().trhip_launch_shard_late_info(self.aux.cuda_stream, self.late_counts[bucket].data_ptr(), self.world, self.rank, shard_info_ptr)
+                if rc != 0:
+                    raise RuntimeError(self.rhi.load().trhip_last_error().decode(errors="replace"))
+                self.late_ready[bucket].record(self.aux)
         except Exception as e:      # a ctypes callback cannot propagate: re-raised by run()
             self._hook_error = e
 

@@ -22,7 +22,7 @@ HOST_SYMBOLS = [
     "trhost_heap_sim", "trhost_set_shard_late_exchange", "trhost_set_gpu_timers",
 ]
 
-SHARD_LATE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int)   # trhost_shard_late_fn
+SHARD_LATE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int)   # trhost_shard_late_fn
 
 
 class PassBuffers(C.Structure):
@@ -172,12 +172,12 @@ class Renderer:
         _check(load().trhost_set_gpu_timers(int(bool(enable))))
 
     def set_shard_late_exchange(self, fn):
-        """Multi-GPU hook (include/trhost.h): fn(hip_stream, late_count_ptr, shard_info_ptr, bucket) runs
-        inside frame() before each late instance cull; None removes it."""
+        """Multi-GPU hook (include/trhost.h): fn(hip_stream, late_count_ptr, shard_info_ptr, bucket, phase) runs inside
+        frame(): phase 0 after each early instance cull, phase 1 before each late one; None removes it."""
         if fn is None:
             self._shard_late_cb = C.cast(None, SHARD_LATE_FN)
         else:
-            self._shard_late_cb = SHARD_LATE_FN(lambda _u, s, c, i, b: fn(int(s or 0), int(c), int(i), int(b)))
+            self._shard_late_cb = SHARD_LATE_FN(lambda _u, s, c, i, b, ph: fn(int(s or 0), int(c), int(i), int(b), int(ph)))
         _check(load().trhost_set_shard_late_exchange(self._shard_late_cb, None))
 
     def pass_buffers(self, slot: int) -> PassBuffers:
