@@ -57,15 +57,6 @@ def build_shard(spec: synth.SceneSpec, rank: int, world: int, renderer, threads:
     end = int(md["m_MeshLODDatas"]["m_MeshletDataBufferIdx"][i1 - 1, 0]) + int(md["m_MeshLODDatas"]["m_NumMeshlets"][i1 - 1].sum())
     n_local = end - base
     inst = synth.gen_instances(spec)
-    if os.environ.get("TR_EXPERIMENT_SORT_INSTANCES"):   # locality upper-bound experiment only (not the benchmark config)
-        w = inst["m_WorldMatrix"]
-        z = -np.minimum(w[:, 3, 2], -1e-3)
-        tx = np.clip(((w[:, 3, 0] / z * 1.358) * 0.5 + 0.5) * 32, 0, 31).astype(np.int64)
-        ty = np.clip(((w[:, 3, 1] / z * 2.414) * -0.5 + 0.5) * 32, 0, 31).astype(np.int64)
-        order = np.argsort(ty * 32 + tx, kind="stable")
-        keep_mesh = inst["m_MeshDataIdx"].copy()
-        inst = inst[order]
-        inst["m_MeshDataIdx"] = keep_mesh
     # rebase the owned meshes' meshlet indices into the local shard
     md_local = md.copy()
     lods = md_local["m_MeshLODDatas"]
