@@ -132,6 +132,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+    # TR_DIST_BACKEND=gloo: several ranks on ONE GPU (tests of the multi-rank logic; RCCL needs a GPU per rank)
+    backend = os.environ.get("TR_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     force_gather = bool(os.environ.get("TR_FORCE_GATHER"))     # exercise the RCCL path with a 1-rank group (tests)
@@ -139,7 +143,10 @@ def main():
         import torch.distributed as dist
         if force_gather and "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29400 + os.getpid() % 500), RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from toyrenderer_amd import host, rhi
     from toyrenderer_amd.gather import HipShardExchange
@@ -169,7 +176,7 @@ def main():
         slot_groups = max(b - a for a, b in (shard_range(spec.num_instances, p, world) for p in range(world))) * groups_per_instance
         gather = HipShardExchange(r, dist, world, rank, slot_groups, pass_slots=(0, 1),
                                   group_capacity=spec.num_instances * groups_per_instance,
-                                  overlap=not os.environ.get("TR_NO_OVERLAP"))
+                                  overlap=not os.environ.get("TR_NO_OVERLAP"), stage_through_host=backend != "nccl")
 
     rec_hist = []
     cpu_t = [0.0, 0.0, 0.0, 0.0]                          # host time spent submitting: frame, exchange (diagnostics, stderr only)
@@ -209,7 +216,7 @@ def main():
     log(f"[rank {rank}] host submission per step: frame {cpu_t[0] / args.steps * 1e3:.3f} ms (record {cpu_t[2] / args.steps:.3f}, submit {cpu_t[3] / args.steps:.3f}), exchange {cpu_t[1] / args.steps * 1e3:.3f} ms; "
         f"all steps submitted after {t_submit * 1e3:.2f} ms of {dt * 1e3:.2f} ms")
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -227,7 +234,7 @@ def main():
         tested += gs_num_meshlets(spec, recs)
     counts = np.array([tested, groups, visible], np.int64)
     if dist is not None:
-        t = torch.tensor(counts, device="cuda")
+        t = torch.tensor(counts, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t)
         counts = t.cpu().numpy()
     tested_all, groups_all, visible_all = (int(x) for x in counts)
@@ -241,6 +248,21 @@ def main():
             g_rec, g_lst = gather.results(s_)
             gather_checked &= bool(np.array_equal(g_rec, res[s_]["records"].view(np.uint32).reshape(-1, 3)))
             gather_checked &= bool(np.array_equal(g_lst, res[s_]["visibleList"]))
+    # digest of the whole-scene results (records + ordered visible lists of both phases): the same for every number of
+    # ranks (tests/test_gpu_host_path.py compares a 1-rank run with a 2-rank run)
+    import hashlib
+    h = hashlib.sha1()
+    for s_ in (0, 1):
+        if gather is not None:
+            if res[s_] is None and gather.results(s_)[0].size == 0:
+                continue
+            g_rec, g_lst = gather.results(s_)
+        elif res[s_] is not None:
+            g_rec, g_lst = res[s_]["records"].view(np.uint32).reshape(-1, 3), res[s_]["visibleList"]
+        else:
+            continue
+        h.update(np.ascontiguousarray(g_rec).tobytes()); h.update(np.ascontiguousarray(g_lst).tobytes())
+    lists_digest = h.hexdigest()
     ms_per_step = dt / args.steps * 1e3
     value = tested_all / (dt / args.steps) / 1e9
 
@@ -298,6 +320,7 @@ def main():
                        "visible_per_frame": visible_all, "culling_flags": args.flags},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        out["lists_digest"] = lists_digest
         if gather_checked is not None:
             out["gather_checked"] = gather_checked
     sync()

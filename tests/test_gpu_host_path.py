@@ -197,3 +197,29 @@ def test_cornell_scene_through_the_drop_in_path(oracle, flags):
         assert np.array_equal(got[s]["visMask"], z[f"f{flags}_s{s}_visMask"]), f"slot {s}: masks"
         assert np.array_equal(got[s]["visibleList"], z[f"f{flags}_s{s}_visibleList"]), f"slot {s}: visible list"
     assert int(got[0]["drawArgs"][0]) == int(ref.drawArgs[0][0]) >= 3
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_sharing_one_gpu_equal_one_rank(world):
+    """bench.py with 2 and 3 ranks (torch.distributed.run, gloo with host-staged collectives because RCCL needs a GPU per
+    rank) sharing this GPU: instance sharding, the in-frame late-count exchange between real ranks, shard-slot
+    all-gather, unpack -- the whole-scene records and visible lists (sha1 digest) must equal a single-rank run's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--config", "C3s", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-profile"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common], capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads(one.stdout.strip().splitlines()[-1])
+    env = dict(os.environ, TR_DIST_BACKEND="gloo")
+    port = 29600 + os.getpid() % 300 + world
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), *common],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    d2 = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert d2["n_gpus"] == world and d2["config"]["meshlets_tested_per_frame"] == d1["config"]["meshlets_tested_per_frame"]
+    assert d2["config"]["visible_per_frame"] == d1["config"]["visible_per_frame"]
+    assert d2["lists_digest"] == d1["lists_digest"], "multi-rank whole-scene lists differ from the 1-rank lists"

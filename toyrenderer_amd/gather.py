@@ -121,12 +121,22 @@ class ShardExchange:
         """Block until every exchange issued so far has completed."""
 
     # ---- per frame ---------------------------------------------------------------------------------
+    def _all_gather(self, out, inp, group=None):
+        """all_gather_into_tensor; with `stage_through_host` (tests that run several ranks on ONE GPU over gloo,
+        where RCCL cannot be used) device tensors take the detour through host memory."""
+        if getattr(self, "stage_through_host", False) and inp.is_cuda:
+            o = self.torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(o, inp.cpu(), group=group)
+            out.copy_(o)
+        else:
+            self.dist.all_gather_into_tensor(out, inp, group=group)
+
     def run(self):
         b = self.frame & 1
         self._begin(b)
         self._pack(b)
         with self._comm(b):
-            self.dist.all_gather_into_tensor(self.recv[b], self.send[b])
+            self._all_gather(self.recv[b], self.send[b])
             self._unpack(b)
         self.frame += 1
 
@@ -167,12 +177,14 @@ class HipShardExchange(ShardExchange):
     unpacks on a second stream (overlap=True) so the next frame's culling runs meanwhile."""
 
     def __init__(self, renderer, dist, world: int, rank: int, slot_groups: int, pass_slots=(0, 1),
-                 group_capacity: int | None = None, list_capacity: int | None = None, overlap: bool = True):
+                 group_capacity: int | None = None, list_capacity: int | None = None, overlap: bool = True,
+                 stage_through_host: bool = False):
         import torch
 
         from . import rhi
         super().__init__(dist, torch, world, rank, slot_groups, pass_slots, group_capacity, list_capacity, device="cuda")
         self.rhi, self.r = rhi, renderer
+        self.stage_through_host = bool(stage_through_host)
         L = rhi.load()
         self.dev = rhi.Device(handle=renderer.device())                       # the renderer's device (compute stream)
         self.compute = torch.cuda.ExternalStream(int(L.trhip_device_stream(self.dev.h) or 0))
@@ -229,7 +241,7 @@ class HipShardExchange(ShardExchange):
             self.late_posted[bucket].record(self.compute)
             with self.torch.cuda.stream(self.aux):
                 self.aux.wait_event(self.late_posted[bucket])
-                self.dist.all_gather_into_tensor(self.late_counts[bucket], t, group=self.late_group)
+                self._all_gather(self.late_counts[bucket], t, group=self.late_group)
                 rc = self.rhi.load().trhip_launch_shard_late_info(self.aux.cuda_stream, self.late_counts[bucket].data_ptr(), self.world, self.rank, shard_info_ptr)
                 if rc != 0:
                     raise RuntimeError(self.rhi.load().trhip_last_error().decode(errors="replace"))
