@@ -198,6 +198,7 @@ class HipShardExchange(ShardExchange):
         self.released = [torch.cuda.Event() for _ in range(2)]
         self.send_buf = [self.dev.wrap_buffer(t.data_ptr(), t.numel() * 4, f"ShardSlotSend{i}") for i, t in enumerate(self.send)]
         self.pack_cl = [self.dev.create_command_list() for _ in range(2)]
+        self._pack_key = [None, None]
         # the unpack only touches buffers owned here: recorded once per buffer index
         self.unpack_cl = []
         push = np.array([self.world, self.slot_groups], np.uint32)
@@ -262,19 +263,22 @@ class HipShardExchange(ShardExchange):
 
     def _pack(self, b):
         rhi = self.rhi
-        binds = [rhi.PUSH(0), rhi.UAV(0, self.send_buf[b])]
-        for s in self.pass_slots:
-            pb = self.r.pass_buffers(s)
-            if not pb.ran:
-                continue
-            for k, h in enumerate((pb.records, pb.vis_mask, pb.dispatch_args, pb.draw_args)):
-                x = rhi.bind(rhi.BIND_STRUCTURED_SRV, 4 * s + k)
-                x.resource = h
-                binds.append(x)
+        pbs = [(s, self.r.pass_buffers(s)) for s in self.pass_slots]
+        key = tuple((s, pb.ran, pb.records, pb.vis_mask, pb.dispatch_args, pb.draw_args) for s, pb in pbs)
         cl = self.pack_cl[b]
-        cl.open()
-        cl.dispatch("visibility_CS_PackShard", binds, (1, 1, 1), push=np.array([self.slot_groups], np.uint32))
-        cl.close()
+        if self._pack_key[b] != key:                    # the render graph hands out the same buffers frame after frame: record once
+            binds = [rhi.PUSH(0), rhi.UAV(0, self.send_buf[b])]
+            for s, pb in pbs:
+                if not pb.ran:
+                    continue
+                for k, h in enumerate((pb.records, pb.vis_mask, pb.dispatch_args, pb.draw_args)):
+                    x = rhi.bind(rhi.BIND_STRUCTURED_SRV, 4 * s + k)
+                    x.resource = h
+                    binds.append(x)
+            cl.open()
+            cl.dispatch("visibility_CS_PackShard", binds, (1, 1, 1), push=np.array([self.slot_groups], np.uint32))
+            cl.close()
+            self._pack_key[b] = key
         self.dev.execute(cl)
         self.packed[b].record(self.compute)
 
