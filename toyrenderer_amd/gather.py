@@ -28,7 +28,8 @@ complete; the compute stream only waits for its event before the late instance c
 hooked into the frame through trhost_set_shard_late_exchange / FrameDriver(shard_late=...)).
 Group-capacity overflow (the reference's 65 535-group cap, Q2) is NOT made global: a sharded run equals
 the single-GPU run only if no rank drops groups; a rank that does raises STATUS_GROUPS_DROPPED.
-torch.distributed is plumbing here (process group + the RCCL calls).
+torch.distributed is plumbing here: it launches the ranks and carries the 128-byte RCCL unique ids; the collectives
+themselves are direct ncclAllGather calls on this module's own communicators and streams (`RcclComm`).
 """
 from __future__ import annotations
 
@@ -136,9 +137,12 @@ class ShardExchange:
         self._begin(b)
         self._pack(b)
         with self._comm(b):
-            self._all_gather(self.recv[b], self.send[b])
+            self._exchange_slots(b)
             self._unpack(b)
         self.frame += 1
+
+    def _exchange_slots(self, b: int):
+        self._all_gather(self.recv[b], self.send[b])
 
     def results(self, pass_slot: int):
         """(records[G,3], visible list[V]) of the whole scene for one pass slot, as u32 (host copy).
@@ -157,6 +161,58 @@ class ShardExchange:
             raise RuntimeError(f"whole-scene visible list holds {self.list_capacity} entries, frame produced {V}")
         return (o["records"][:3 * G].cpu().numpy().view(np.uint32).reshape(-1, 3),
                 o["list"][:V].cpu().numpy().view(np.uint32))
+
+
+class RcclComm:
+    """One RCCL communicator driven directly (ctypes on the librccl torch already loaded): a collective is ONE
+    ncclAllGather on the stream it belongs to -- no detour over the process group's stream, no tensor bookkeeping;
+    the process group only carries the 128-byte unique id at set-up.  Every rank must construct it, in the same order."""
+
+    _lib = None
+
+    @classmethod
+    def lib(cls, torch):
+        if cls._lib is None:
+            import ctypes as C
+            import os
+            path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            L = C.CDLL(path if os.path.exists(path) else "librccl.so")
+
+            class UniqueId(C.Structure):
+                _fields_ = [("internal", C.c_ubyte * 128)]
+            L.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+            L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+            L.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+            L.ncclCommDestroy.argtypes = [C.c_void_p]
+            L.ncclGetErrorString.restype = C.c_char_p
+            L.ncclGetErrorString.argtypes = [C.c_int]
+            cls._lib, cls._UniqueId = L, UniqueId
+        return cls._lib
+
+    def __init__(self, dist, torch, world: int, rank: int):
+        import ctypes as C
+        L = self.lib(torch)
+        uid = self._UniqueId()
+        if rank == 0:
+            self._check(L.ncclGetUniqueId(C.byref(uid)))
+        t = torch.frombuffer(bytearray(C.string_at(C.byref(uid), 128)), dtype=torch.uint8).cuda()   # all 128 bytes (zeros on ranks > 0)
+        dist.broadcast(t, src=0)                            # the process group carries the id, nothing else
+        raw = bytes(t.cpu().numpy().tobytes())
+        C.memmove(C.byref(uid), raw, 128)
+        self.comm = C.c_void_p()
+        self._check(L.ncclCommInitRank(C.byref(self.comm), int(world), uid, int(rank)))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError("RCCL: " + self._lib.ncclGetErrorString(rc).decode(errors="replace"))
+
+    def all_gather_i32(self, send_ptr: int, recv_ptr: int, count: int, stream_ptr: int):
+        self._check(self._lib.ncclAllGather(send_ptr, recv_ptr, int(count), 2, self.comm, stream_ptr))   # 2 = ncclInt32
+
+    def destroy(self):
+        if self.comm:
+            self._lib.ncclCommDestroy(self.comm)
+            self.comm = None
 
 
 class _DevWords:
@@ -219,7 +275,10 @@ class HipShardExchange(ShardExchange):
         self.late_counts = [torch.zeros(self.world, dtype=torch.int32, device="cuda") for _ in range(2)]
         # its own communicator: the 4-byte in-frame collective must not queue behind the previous frame's slot
         # exchange on the process group's stream (every rank creates the group, in the same order)
-        self.late_group = dist.new_group()
+        self.late_group = dist.new_group() if self.stage_through_host else None
+        # RCCL proper: two communicators of our own (slot exchange on the comm stream, late counts on the auxiliary one)
+        self.rccl_slots = None if self.stage_through_host else RcclComm(dist, torch, self.world, self.rank)
+        self.rccl_late = None if self.stage_through_host else RcclComm(dist, torch, self.world, self.rank)
         self.aux = torch.cuda.Stream()
         self.late_posted = [torch.cuda.Event() for _ in range(2)]
         self.late_ready = [torch.cuda.Event() for _ in range(2)]
@@ -242,7 +301,10 @@ class HipShardExchange(ShardExchange):
             self.late_posted[bucket].record(self.compute)
             with self.torch.cuda.stream(self.aux):
                 self.aux.wait_event(self.late_posted[bucket])
-                self._all_gather(self.late_counts[bucket], t, group=self.late_group)
+                if self.rccl_late is not None:
+                    self.rccl_late.all_gather_i32(late_count_ptr, self.late_counts[bucket].data_ptr(), 1, self.aux.cuda_stream)
+                else:
+                    self._all_gather(self.late_counts[bucket], t, group=self.late_group)
                 rc = self.rhi.load().trhip_launch_shard_late_info(self.aux.cuda_stream, self.late_counts[bucket].data_ptr(), self.world, self.rank, shard_info_ptr)
                 if rc != 0:
                     raise RuntimeError(self.rhi.load().trhip_last_error().decode(errors="replace"))
@@ -289,6 +351,12 @@ class HipShardExchange(ShardExchange):
             yield
             self.released[b].record(self.comm)
 
+    def _exchange_slots(self, b):
+        if self.rccl_slots is not None:
+            self.rccl_slots.all_gather_i32(self.send[b].data_ptr(), self.recv[b].data_ptr(), self.slot_words, self.comm.cuda_stream)
+        else:
+            self._all_gather(self.recv[b], self.send[b])
+
     def _unpack(self, b):
         self.comm_dev.execute(self.unpack_cl[b])
 
@@ -297,7 +365,11 @@ class HipShardExchange(ShardExchange):
 
     def close(self):
         self.wait()
+        self.aux.synchronize()
         self.r.set_shard_late_exchange(None)
+        for c in (self.rccl_slots, self.rccl_late):
+            if c is not None:
+                c.destroy()
         for cl in self.pack_cl + self.unpack_cl:
             cl.release()
         for buf in self.send_buf + self._wrapped:
