@@ -275,10 +275,27 @@ class HipShardExchange(ShardExchange):
         self.late_counts = [torch.zeros(self.world, dtype=torch.int32, device="cuda") for _ in range(2)]
         # its own communicator: the 4-byte in-frame collective must not queue behind the previous frame's slot
         # exchange on the process group's stream (every rank creates the group, in the same order)
-        self.late_group = dist.new_group() if self.stage_through_host else None
-        # RCCL proper: two communicators of our own (slot exchange on the comm stream, late counts on the auxiliary one)
-        self.rccl_slots = None if self.stage_through_host else RcclComm(dist, torch, self.world, self.rank)
-        self.rccl_late = None if self.stage_through_host else RcclComm(dist, torch, self.world, self.rank)
+        # RCCL proper: two communicators of our own (slot exchange on the comm stream, late counts on the auxiliary one).
+        # Should their set-up fail on every rank alike (library / symbol trouble), the process group's collectives do
+        # the job instead -- slower per call, same results; the ranks agree on that with one all-reduce.
+        self.rccl_slots = self.rccl_late = None
+        if not self.stage_through_host:
+            ok = 1
+            try:
+                self.rccl_slots = RcclComm(dist, torch, self.world, self.rank)
+                self.rccl_late = RcclComm(dist, torch, self.world, self.rank)
+            except (OSError, AttributeError, RuntimeError) as e:
+                import sys
+                print(f"[rank {rank}] direct RCCL communicators unavailable ({e}); using the process group", file=sys.stderr, flush=True)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                for c in (self.rccl_slots, self.rccl_late):
+                    if c is not None:
+                        c.destroy()
+                self.rccl_slots = self.rccl_late = None
+        self.late_group = dist.new_group() if self.rccl_late is None else None
         self.aux = torch.cuda.Stream()
         self.late_posted = [torch.cuda.Event() for _ in range(2)]
         self.late_ready = [torch.cuda.Event() for _ in range(2)]
