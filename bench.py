@@ -149,7 +149,7 @@ def main():
             dist.init_process_group(backend)
 
     from toyrenderer_amd import host, rhi
-    from toyrenderer_amd.gather import HipShardExchange
+    from toyrenderer_amd.gather import NativeShardExchange
 
     # the HIP back end's stream = torch's current stream; (N > 1) the exchange adds its own second stream
     side = torch.cuda.Stream()
@@ -174,7 +174,7 @@ def main():
     if dist is not None:
         # one slot size for all ranks: the largest shard, every instance submitted at LOD 0
         slot_groups = max(b - a for a, b in (shard_range(spec.num_instances, p, world) for p in range(world))) * groups_per_instance
-        gather = HipShardExchange(r, dist, world, rank, slot_groups, pass_slots=(0, 1),
+        gather = NativeShardExchange(r, dist, world, rank, slot_groups, pass_slots=(0, 1),
                                   group_capacity=spec.num_instances * groups_per_instance,
                                   overlap=not os.environ.get("TR_NO_OVERLAP"), stage_through_host=backend != "nccl")
 

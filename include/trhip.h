@@ -190,6 +190,17 @@ int  trhip_profile_reset(trhip_device dev);
 int  trhip_profile_count(trhip_device dev, uint32_t* n);
 int  trhip_profile_entry(trhip_device dev, uint32_t index, const char** name, uint64_t* launches, double* total_ms);
 
+/* Streams and events for callers that order work across streams themselves (the multi-GPU exchange runs on its own
+ * streams next to the renderer's).  Plain wrappers: hipStreamCreateWithFlags(NonBlocking), hipEventCreateWithFlags
+ * (DisableTiming), hipEventRecord, hipStreamWaitEvent, hipStreamSynchronize. */
+int  trhip_stream_create(int device_index, void** out_hip_stream);
+void trhip_stream_destroy(void* hip_stream);
+int  trhip_stream_synchronize(void* hip_stream);
+int  trhip_event_create(int device_index, void** out_hip_event);
+void trhip_event_destroy(void* hip_event);
+int  trhip_event_record(void* hip_event, void* hip_stream);
+int  trhip_stream_wait_event(void* hip_stream, void* hip_event);
+
 /* Multi-GPU late phase.  The reference sizes the late instance cull from the late-list length
  * (gpuculling.hlsl:182-195, Q1: ceil(count/64) groups of 32 threads).  With the instance list sharded
  * over ranks that rule has to see the WHOLE scene's late list: every rank all-gathers its late count,

@@ -86,6 +86,30 @@ void* trhost_device(void);     /* the trhip_device in use                       
 typedef void (*trhost_shard_late_fn)(void* user, void* hip_stream, void* late_count, void* shard_info, int bucket, int phase);
 int  trhost_set_shard_late_exchange(trhost_shard_late_fn fn, void* user);
 
+/* Native per-frame driver of the multi-GPU exchange (protocol: toyrenderer_amd/gather.py).
+ * The collectives are callbacks so that the library needs no RCCL at link time: all-gather `count_words` 32-bit words
+ * from `send` of every rank into `recv` (rank-major), enqueued on `hip_stream`; return 0 on success.
+ * trhost_rccl_allgather is the ready-made binding: user = void*[2] { address of ncclAllGather, the ncclComm_t }. */
+typedef int (*trhost_allgather_fn)(void* user, const void* send, void* recv, uint64_t count_words, void* hip_stream);
+int  trhost_rccl_allgather(void* user, const void* send, void* recv, uint64_t count_words, void* hip_stream);
+typedef struct trhost_exchange_desc {
+    uint32_t world, rank;
+    uint32_t slot_groups;            /* groups one rank's shard slot holds (the same on every rank)                 */
+    uint32_t group_capacity;         /* whole-scene outputs, groups (0: world * slot_groups)                        */
+    uint64_t list_capacity;          /* whole-scene visible list, entries (0: 32 * group_capacity)                  */
+    uint32_t pass_slot_mask;         /* bit s: gather pass slot s (0 early-opaque, 1 late-opaque, 2/3 alpha mask)   */
+    int      overlap;                /* 1: gather + unpack on their own stream, overlapping the next frame          */
+    trhost_allgather_fn slots_allgather; void* slots_user;     /* shard slots, once per frame                       */
+    trhost_allgather_fn late_allgather;  void* late_user;      /* late-list lengths, inside the frame (1 word)      */
+} trhost_exchange_desc;
+int  trhost_exchange_create(const trhost_exchange_desc* desc);   /* also installs the in-frame late-count hook      */
+int  trhost_exchange_run(void);                                  /* after trhost_frame: pack, gather, unpack (async) */
+int  trhost_exchange_wait(void);
+/* trhip_buffer handles of the whole-scene results of a pass slot: records, lane masks, ordered visible list,
+ * args (8 words: {G,1,1,G}, {V,1,1}, status bits as in gather.py). */
+int  trhost_exchange_outputs(uint32_t pass_slot, void** records, void** masks, void** list, void** args);
+int  trhost_exchange_destroy(void);
+
 int  trhost_render_graph_stats(uint32_t* num_heaps, uint64_t* bytes_reserved, uint64_t* bytes_used, uint32_t* num_passes);
 /* renderer_name "<frame>": host milliseconds the last trhost_frame spent recording (cpu_ms) and submitting (gpu_ms). */
 int  trhost_renderer_times(const char* renderer_name, float* cpu_ms, float* gpu_ms);

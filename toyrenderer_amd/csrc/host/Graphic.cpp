@@ -42,6 +42,7 @@ Graphic& Graphic::GetInstance()
 void Graphic::Initialize(int deviceIndex, Vector2U renderResolution, void* externalHipStream)
 {
     m_RenderResolution = renderResolution;                                   // Graphic.cpp:612
+    m_DeviceIndex = deviceIndex;
     m_NVRHIDevice = GraphicRHI::CreateDevice(deviceIndex, externalHipStream); // InitDevice
     // InitShaders (Graphic.cpp:103-251) loads DXIL blobs into a name->shader map; here the kernels are
     // linked into the back end and registered under the same names.

@@ -89,6 +89,7 @@ public:
 
     Vector2U m_RenderResolution{ 0, 0 };
     uint32_t m_FrameCounter = 0;
+    int m_DeviceIndex = 0;
     bool m_bEnableGPUTimers = true;                                          // per-renderer timer queries (RenderGraph.cpp:262-281); instrumentation only
     float m_LastRecordMs = 0.f, m_LastSubmitMs = 0.f;                      // host time of the last Update(): recording, submission
     // this build: capacity of the amplification-record buffer.  The reference hard-codes

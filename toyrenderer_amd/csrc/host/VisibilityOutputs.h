@@ -24,3 +24,11 @@ void ReleaseVisibilityPassBuffers();
 // the frame is submitted: after each early instance cull (phase 0) and before each late one (phase 1).
 using ShardLateFn = void (*)(void* user, void* hipStream, void* lateCount, void* shardInfo, int bucket, int phase);
 void SetShardLateExchange(ShardLateFn fn, void* user);
+
+// Native per-frame driver of the multi-GPU exchange (ShardExchange.cpp; C facade in trhost.h).
+struct trhost_exchange_desc;
+void ShardExchangeCreate(const trhost_exchange_desc& desc);
+void ShardExchangeRun();
+void ShardExchangeWait();
+void ShardExchangeOutputs(uint32_t slot, void** records, void** masks, void** list, void** args);
+void ShardExchangeDestroy();

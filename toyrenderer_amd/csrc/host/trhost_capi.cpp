@@ -53,6 +53,7 @@ void trhost_shutdown(void)
 {
     if (!s_Initialized) return;
     (void)guarded([&] {
+        ShardExchangeDestroy();
         ReleaseVisibilityPassBuffers();
         g_Graphic.Shutdown();
     });
@@ -187,6 +188,18 @@ int trhost_set_shard_late_exchange(trhost_shard_late_fn fn, void* user)
 {
     return guarded([&] { SetShardLateExchange(fn, user); });
 }
+
+int trhost_exchange_create(const trhost_exchange_desc* desc)
+{
+    return guarded([&] { check(desc); ShardExchangeCreate(*desc); });
+}
+int trhost_exchange_run(void) { return guarded([&] { ShardExchangeRun(); }); }
+int trhost_exchange_wait(void) { return guarded([&] { ShardExchangeWait(); }); }
+int trhost_exchange_outputs(uint32_t pass_slot, void** records, void** masks, void** list, void** args)
+{
+    return guarded([&] { check(records && masks && list && args); ShardExchangeOutputs(pass_slot, records, masks, list, args); });
+}
+int trhost_exchange_destroy(void) { return guarded([&] { ShardExchangeDestroy(); }); }
 
 int trhost_render_graph_stats(uint32_t* num_heaps, uint64_t* bytes_reserved, uint64_t* bytes_used, uint32_t* num_passes)
 {

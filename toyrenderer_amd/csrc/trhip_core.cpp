@@ -840,6 +840,57 @@ int trhip_queue_execute(trhip_device dev, const trhip_cmdlist* lists, uint32_t n
     return endRun();
 }
 
+// ---- streams / events for callers that order work across streams themselves ------------------------------
+int trhip_stream_create(int device_index, void** out)
+{
+    if (!out) return fail(TRHIP_ERR_INVALID, "stream_create: out is null");
+    TRHIP_HIP(hipSetDevice(device_index));
+    hipStream_t s = nullptr;
+    TRHIP_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = (void*)s;
+    return TRHIP_OK;
+}
+
+void trhip_stream_destroy(void* s)
+{
+    if (s) { (void)hipStreamSynchronize((hipStream_t)s); (void)hipStreamDestroy((hipStream_t)s); }
+}
+
+int trhip_stream_synchronize(void* s)
+{
+    TRHIP_HIP(hipStreamSynchronize((hipStream_t)s));
+    return TRHIP_OK;
+}
+
+int trhip_event_create(int device_index, void** out)
+{
+    if (!out) return fail(TRHIP_ERR_INVALID, "event_create: out is null");
+    TRHIP_HIP(hipSetDevice(device_index));
+    hipEvent_t e = nullptr;
+    TRHIP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *out = (void*)e;
+    return TRHIP_OK;
+}
+
+void trhip_event_destroy(void* e)
+{
+    if (e) (void)hipEventDestroy((hipEvent_t)e);
+}
+
+int trhip_event_record(void* e, void* s)
+{
+    if (!e) return fail(TRHIP_ERR_INVALID, "event_record: event is null");
+    TRHIP_HIP(hipEventRecord((hipEvent_t)e, (hipStream_t)s));
+    return TRHIP_OK;
+}
+
+int trhip_stream_wait_event(void* s, void* e)
+{
+    if (!e) return fail(TRHIP_ERR_INVALID, "stream_wait_event: event is null");
+    TRHIP_HIP(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)e, 0));
+    return TRHIP_OK;
+}
+
 // ---- timers / profile ----------------------------------------------------------------------------
 int trhip_timer_create(trhip_device dev, trhip_timer* out)
 {

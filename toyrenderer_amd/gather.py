@@ -81,7 +81,8 @@ def agree_slot_groups(dist, torch, local_capacity: int, device="cpu") -> int:
 class ShardExchange:
     """Host logic of the exchange (buffers, double buffering, the one collective per frame).  The data
     movers are hooks: `_pack(b)` fills send[b] from the local pass slots, `_unpack(b)` turns recv[b] into
-    the whole-scene outputs.  HipShardExchange implements them with the gfx950 kernels."""
+    the whole-scene outputs.  It is the PROTOCOL stated in Python (CPU tests run it over gloo with the numpy movers of
+    tests/exchange_ref.py); on the GPU the same sequence is driven natively (NativeShardExchange, ShardExchange.cpp)."""
 
     def __init__(self, dist, torch, world: int, rank: int, slot_groups: int, pass_slots=(0, 1),
                  group_capacity: int | None = None, list_capacity: int | None = None, device="cpu"):
@@ -228,168 +229,93 @@ def shard_late_info(counts, rank: int):
     return sum(counts[:rank]), sum(counts)
 
 
-class HipShardExchange(ShardExchange):
-    """GPU path over the C++ host mirror: packs the renderer's pass slots on its stream, gathers and
-    unpacks on a second stream (overlap=True) so the next frame's culling runs meanwhile."""
+class NativeShardExchange:
+    """GPU path: the exchange is driven natively by the host library (csrc/host/ShardExchange.cpp: pack on the
+    renderer's stream, one all-gather, unpack + list rebuild on the exchange stream, in-frame late-count exchange on
+    an auxiliary stream); per frame Python makes ONE call.  This class only sets it up: with RCCL it creates two
+    communicators (`RcclComm`) and hands their ncclAllGather to the library; for tests that run several ranks on one
+    GPU (`stage_through_host`, any torch.distributed backend) the collectives are host-staged callbacks."""
 
     def __init__(self, renderer, dist, world: int, rank: int, slot_groups: int, pass_slots=(0, 1),
                  group_capacity: int | None = None, list_capacity: int | None = None, overlap: bool = True,
                  stage_through_host: bool = False):
+        import ctypes as C
+
         import torch
 
-        from . import rhi
-        super().__init__(dist, torch, world, rank, slot_groups, pass_slots, group_capacity, list_capacity, device="cuda")
-        self.rhi, self.r = rhi, renderer
-        self.stage_through_host = bool(stage_through_host)
-        L = rhi.load()
-        self.dev = rhi.Device(handle=renderer.device())                       # the renderer's device (compute stream)
-        self.compute = torch.cuda.ExternalStream(int(L.trhip_device_stream(self.dev.h) or 0))
-        self.overlap = bool(overlap)
-        if self.overlap:
-            self.comm = torch.cuda.Stream()
-            self.comm_dev = rhi.Device(torch.cuda.current_device(), stream=self.comm.cuda_stream)
+        from . import host, rhi
+        self.torch, self.dist, self.host, self.rhi = torch, dist, host, rhi
+        self.world, self.rank, self.pass_slots = int(world), int(rank), tuple(pass_slots)
+        self.list_capacity = int(list_capacity if list_capacity is not None else 32 * (group_capacity if group_capacity is not None else world * slot_groups))
+        self.group_capacity = int(group_capacity if group_capacity is not None else world * slot_groups)
+        L = host.load()
+        self._keep = []
+        d = host.ExchangeDesc()
+        d.world, d.rank, d.slot_groups, d.group_capacity = self.world, self.rank, int(slot_groups), self.group_capacity
+        d.list_capacity, d.overlap = self.list_capacity, int(bool(overlap))
+        d.pass_slot_mask = sum(1 << s for s in self.pass_slots)
+        self.comms = []
+        if stage_through_host:
+            groups = [dist.new_group(), dist.new_group()]
+
+            def staged(group):
+                def fn(_user, send, recv, count, stream):
+                    try:
+                        torch.cuda.ExternalStream(int(stream or 0)).synchronize()
+                        src = torch.as_tensor(_DevWords(int(send), int(count)), device="cuda").cpu()
+                        out = torch.empty(int(count) * self.world, dtype=torch.int32)
+                        dist.all_gather_into_tensor(out, src, group=group)
+                        torch.as_tensor(_DevWords(int(recv), int(count) * self.world), device="cuda").copy_(out)
+                        torch.cuda.current_stream().synchronize()
+                        return 0
+                    except Exception as e:          # a ctypes callback cannot propagate
+                        import sys
+                        print(f"[rank {rank}] staged all-gather failed: {e}", file=sys.stderr, flush=True)
+                        return 1
+                cb = host.ALLGATHER_FN(fn)
+                self._keep.append(cb)
+                return C.cast(cb, C.c_void_p).value
+            d.slots_allgather, d.late_allgather = staged(groups[0]), staged(groups[1])
         else:
-            self.comm, self.comm_dev = self.compute, self.dev
-        self.packed = [torch.cuda.Event() for _ in range(2)]
-        self.released = [torch.cuda.Event() for _ in range(2)]
-        self.send_buf = [self.dev.wrap_buffer(t.data_ptr(), t.numel() * 4, f"ShardSlotSend{i}") for i, t in enumerate(self.send)]
-        self.pack_cl = [self.dev.create_command_list() for _ in range(2)]
-        self._pack_key = [None, None]
-        # the unpack only touches buffers owned here: recorded once per buffer index
-        self.unpack_cl = []
-        push = np.array([self.world, self.slot_groups], np.uint32)
-        self._wrapped = []
-        for b in range(2):
-            cl = self.comm_dev.create_command_list()
-            binds = [rhi.PUSH(0), rhi.SRV(0, self._wrap(self.recv[b], f"ShardSlotsRecv{b}"))]
-            for s in self.pass_slots:
-                o = self.out[s]
-                binds += [rhi.UAV(4 * s, self._wrap(o["records"], f"AllRecords{s}")), rhi.UAV(4 * s + 1, self._wrap(o["masks"], f"AllMasks{s}")),
-                          rhi.UAV(4 * s + 2, self._wrap(o["list"], f"AllVisibleList{s}")), rhi.UAV(4 * s + 3, self._wrap(o["args"], f"AllArgs{s}"))]
-            cl.open()
-            cl.dispatch("visibility_CS_UnpackShards", binds, (1, 1, 1), push=push)
-            cl.close()
-            self.unpack_cl.append(cl)
+            R = RcclComm.lib(torch)
+            fn_addr = C.cast(L.trhost_rccl_allgather, C.c_void_p).value
+            for _ in range(2):
+                comm = RcclComm(dist, torch, self.world, self.rank)
+                user = (C.c_void_p * 2)(C.cast(R.ncclAllGather, C.c_void_p).value, comm.comm.value)
+                self.comms.append(comm)
+                self._keep.append(user)
+            d.slots_allgather, d.slots_user = fn_addr, C.cast(self._keep[0], C.c_void_p).value
+            d.late_allgather, d.late_user = fn_addr, C.cast(self._keep[1], C.c_void_p).value
+        host._check(L.trhost_exchange_create(C.byref(d)))
+        self._L = L
 
-        # in-frame exchange of the late-list lengths (module docstring)
-        self.late_counts = [torch.zeros(self.world, dtype=torch.int32, device="cuda") for _ in range(2)]
-        # its own communicator: the 4-byte in-frame collective must not queue behind the previous frame's slot
-        # exchange on the process group's stream (every rank creates the group, in the same order)
-        # RCCL proper: two communicators of our own (slot exchange on the comm stream, late counts on the auxiliary one).
-        # Should their set-up fail on every rank alike (library / symbol trouble), the process group's collectives do
-        # the job instead -- slower per call, same results; the ranks agree on that with one all-reduce.
-        self.rccl_slots = self.rccl_late = None
-        if not self.stage_through_host:
-            ok = 1
-            try:
-                self.rccl_slots = RcclComm(dist, torch, self.world, self.rank)
-                self.rccl_late = RcclComm(dist, torch, self.world, self.rank)
-            except (OSError, AttributeError, RuntimeError) as e:
-                import sys
-                print(f"[rank {rank}] direct RCCL communicators unavailable ({e}); using the process group", file=sys.stderr, flush=True)
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                for c in (self.rccl_slots, self.rccl_late):
-                    if c is not None:
-                        c.destroy()
-                self.rccl_slots = self.rccl_late = None
-        self.late_group = dist.new_group() if self.rccl_late is None else None
-        self.aux = torch.cuda.Stream()
-        self.late_posted = [torch.cuda.Event() for _ in range(2)]
-        self.late_ready = [torch.cuda.Event() for _ in range(2)]
-        self._ptr_views = {}
-        self._hook_error = None
-        renderer.set_shard_late_exchange(self.late_exchange)
-
-    def late_exchange(self, hip_stream: int, late_count_ptr: int, shard_info_ptr: int, bucket: int, phase: int):
-        """Runs inside renderer.frame() (include/trhost.h).  Phase 0, right after the early instance cull: the
-        all-gather of the late counts and the {lower ranks, all ranks} kernel go to the auxiliary stream, behind an
-        event on the compute stream -- they complete while the early meshlet cull runs.  Phase 1, right before the late
-        instance cull: the compute stream waits for that result."""
-        try:
-            if phase == 1:
-                self.compute.wait_event(self.late_ready[bucket])
-                return
-            t = self._ptr_views.get(late_count_ptr)
-            if t is None:
-                t = self._ptr_views[late_count_ptr] = self.torch.as_tensor(_DevWords(late_count_ptr, 1), device="cuda")
-            self.late_posted[bucket].record(self.compute)
-            with self.torch.cuda.stream(self.aux):
-                self.aux.wait_event(self.late_posted[bucket])
-                if self.rccl_late is not None:
-                    self.rccl_late.all_gather_i32(late_count_ptr, self.late_counts[bucket].data_ptr(), 1, self.aux.cuda_stream)
-                else:
-                    self._all_gather(self.late_counts[bucket], t, group=self.late_group)
-                rc = self.rhi.load().trhip_launch_shard_late_info(self.aux.cuda_stream, self.late_counts[bucket].data_ptr(), self.world, self.rank, shard_info_ptr)
-                if rc != 0:
-                    raise RuntimeError(self.rhi.load().trhip_last_error().decode(errors="replace"))
-                self.late_ready[bucket].record(self.aux)
-        except Exception as e:      # a ctypes callback cannot propagate: re-raised by run()
-            self._hook_error = e
-
-    def _wrap(self, t, name):
-        buf = self.comm_dev.wrap_buffer(t.data_ptr(), t.numel() * 4, name)
-        self._wrapped.append(buf)
-        return buf
-
-    def _begin(self, b):
-        if self._hook_error is not None:
-            e, self._hook_error = self._hook_error, None
-            raise e
-        self.compute.wait_event(self.released[b])
-
-    def _pack(self, b):
-        rhi = self.rhi
-        pbs = [(s, self.r.pass_buffers(s)) for s in self.pass_slots]
-        key = tuple((s, pb.ran, pb.records, pb.vis_mask, pb.dispatch_args, pb.draw_args) for s, pb in pbs)
-        cl = self.pack_cl[b]
-        if self._pack_key[b] != key:                    # the render graph hands out the same buffers frame after frame: record once
-            binds = [rhi.PUSH(0), rhi.UAV(0, self.send_buf[b])]
-            for s, pb in pbs:
-                if not pb.ran:
-                    continue
-                for k, h in enumerate((pb.records, pb.vis_mask, pb.dispatch_args, pb.draw_args)):
-                    x = rhi.bind(rhi.BIND_STRUCTURED_SRV, 4 * s + k)
-                    x.resource = h
-                    binds.append(x)
-            cl.open()
-            cl.dispatch("visibility_CS_PackShard", binds, (1, 1, 1), push=np.array([self.slot_groups], np.uint32))
-            cl.close()
-            self._pack_key[b] = key
-        self.dev.execute(cl)
-        self.packed[b].record(self.compute)
-
-    @contextlib.contextmanager
-    def _comm(self, b):
-        self.comm.wait_event(self.packed[b])
-        with self.torch.cuda.stream(self.comm):
-            yield
-            self.released[b].record(self.comm)
-
-    def _exchange_slots(self, b):
-        if self.rccl_slots is not None:
-            self.rccl_slots.all_gather_i32(self.send[b].data_ptr(), self.recv[b].data_ptr(), self.slot_words, self.comm.cuda_stream)
-        else:
-            self._all_gather(self.recv[b], self.send[b])
-
-    def _unpack(self, b):
-        self.comm_dev.execute(self.unpack_cl[b])
+    def run(self):
+        self.host._check(self._L.trhost_exchange_run())
 
     def wait(self):
-        self.comm.synchronize()
+        self.host._check(self._L.trhost_exchange_wait())
+
+    def results(self, pass_slot: int):
+        """(records[G,3], visible list[V]) of the whole scene for one pass slot, as u32 (host copy).
+        Raises if a slot or the whole-scene buffers overflowed or a rank dropped groups."""
+        import ctypes as C
+        self.wait()
+        h = [C.c_void_p() for _ in range(4)]
+        self.host._check(self._L.trhost_exchange_outputs(int(pass_slot), *[C.byref(x) for x in h]))
+        args = self.host._download(h[3].value, np.uint32, 8)
+        G, V, status = int(args[0]), int(args[4]), int(args[7])
+        if status:
+            raise RuntimeError(f"shard exchange failed (status {status}): "
+                               + ("a rank's groups exceed slot_groups; " if status & STATUS_SLOT_OVERFLOW else "")
+                               + ("whole-scene capacity exceeded; " if status & STATUS_CAPACITY else "")
+                               + ("corrupt slot header; " if status & STATUS_BAD_HEADER else "")
+                               + ("a rank dropped groups at its capacity (Q2)" if status & STATUS_GROUPS_DROPPED else ""))
+        if V > self.list_capacity:
+            raise RuntimeError(f"whole-scene visible list holds {self.list_capacity} entries, frame produced {V}")
+        return (self.host._download(h[0].value, np.uint32, 3 * G).reshape(-1, 3), self.host._download(h[2].value, np.uint32, V))
 
     def close(self):
-        self.wait()
-        self.aux.synchronize()
-        self.r.set_shard_late_exchange(None)
-        for c in (self.rccl_slots, self.rccl_late):
-            if c is not None:
-                c.destroy()
-        for cl in self.pack_cl + self.unpack_cl:
-            cl.release()
-        for buf in self.send_buf + self._wrapped:
-            buf.release()
-        if self.overlap:
-            self.comm_dev.destroy()
+        self.host._check(self._L.trhost_exchange_destroy())
+        for c in self.comms:
+            c.destroy()
+        self.comms = []

@@ -20,7 +20,18 @@ HOST_SYMBOLS = [
     "trhost_upload_hzb_mip", "trhost_download_hzb_mip", "trhost_hzb_info", "trhost_frame", "trhost_wait_idle",
     "trhost_pass_buffers", "trhost_instance_buffer", "trhost_device", "trhost_render_graph_stats", "trhost_renderer_times",
     "trhost_heap_sim", "trhost_set_shard_late_exchange", "trhost_set_gpu_timers",
+    "trhost_rccl_allgather", "trhost_exchange_create", "trhost_exchange_run", "trhost_exchange_wait", "trhost_exchange_outputs",
+    "trhost_exchange_destroy",
 ]
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)   # trhost_allgather_fn
+
+
+class ExchangeDesc(C.Structure):
+    _fields_ = [("world", C.c_uint32), ("rank", C.c_uint32), ("slot_groups", C.c_uint32), ("group_capacity", C.c_uint32),
+                ("list_capacity", C.c_uint64), ("pass_slot_mask", C.c_uint32), ("overlap", C.c_int),
+                ("slots_allgather", C.c_void_p), ("slots_user", C.c_void_p), ("late_allgather", C.c_void_p), ("late_user", C.c_void_p)]
+
 
 SHARD_LATE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int)   # trhost_shard_late_fn
 
@@ -66,6 +77,8 @@ def load() -> C.CDLL:
     L.trhost_render_graph_stats.argtypes = [C.POINTER(u32), C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
     L.trhost_renderer_times.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.trhost_set_gpu_timers.argtypes = [C.c_int]
+    L.trhost_exchange_create.argtypes = [C.POINTER(ExchangeDesc)]
+    L.trhost_exchange_outputs.argtypes = [u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.trhost_set_shard_late_exchange.argtypes = [SHARD_LATE_FN, vp]
     L.trhost_heap_sim.argtypes = [u64, vp, u32, vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
     _lib = L

@@ -36,6 +36,8 @@ ABI_SYMBOLS = [
     "trhip_timer_create", "trhip_timer_release", "trhip_timer_get_ms",
     "trhip_profile_enable", "trhip_profile_reset", "trhip_profile_count", "trhip_profile_entry",
     "trhip_launch_shard_late_info",
+    "trhip_stream_create", "trhip_stream_destroy", "trhip_stream_synchronize", "trhip_event_create", "trhip_event_destroy",
+    "trhip_event_record", "trhip_stream_wait_event",
 ]
 
 HOST_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)       # trhip_host_fn(user, hip_stream)
@@ -125,6 +127,15 @@ def load() -> C.CDLL:
     L.trhip_cmd_copy_texture.argtypes = [vp, vp, vp]
     L.trhip_cmd_host_callback.argtypes = [vp, HOST_FN, vp]
     L.trhip_launch_shard_late_info.argtypes = [vp, vp, u32, u32, vp]
+    L.trhip_stream_create.argtypes = [i32, C.POINTER(vp)]
+    L.trhip_stream_destroy.argtypes = [vp]
+    L.trhip_stream_destroy.restype = None
+    L.trhip_stream_synchronize.argtypes = [vp]
+    L.trhip_event_create.argtypes = [i32, C.POINTER(vp)]
+    L.trhip_event_destroy.argtypes = [vp]
+    L.trhip_event_destroy.restype = None
+    L.trhip_event_record.argtypes = [vp, vp]
+    L.trhip_stream_wait_event.argtypes = [vp, vp]
     L.trhip_cmd_dispatch.argtypes = [vp, C.c_char_p, C.POINTER(Binding), u32, vp, u32, u32, u32, u32]
     L.trhip_cmd_dispatch_indirect.argtypes = [vp, C.c_char_p, C.POINTER(Binding), u32, vp, u32, vp, u32]
     L.trhip_cmd_begin_timer.argtypes = [vp, vp]
