@@ -53,7 +53,11 @@ uint32_t    trhip_abi_version(void);
  * "gpuculling_CS_BuildLateCullIndirectArgs", "minmaxdownsample_CS_Main",
  * "ffx_spd_downsample_pass_CS FFX_SPD_OPTION_DOWNSAMPLE_FILTER=1|2",
  * "updateinstanceconsts_CS_UpdateInstanceConstsAndBuildTLAS", and the compute replacement of the
- * amplification shader: "basepass_AS_Main LATE_CULL=0|1" (alias "basepass_AS_Main_cull"). */
+ * amplification shader: "basepass_AS_Main LATE_CULL=0|1" (alias "basepass_AS_Main_cull").
+ * "basepass_MS_Main_depth" (basepass.hlsl:124-188 + raster + depth test, depth only): b0 BasePassConstants,
+ * t0 instances, t1 vertices (RawVertexFormat, 20 B), t2 mesh data, t4 meshlets, t5 meshlet vertex ids,
+ * t6 packed meshlet triangles, t7 amplification records, t9 visible list, u0 (texture) R32_FLOAT depth;
+ * dispatched indirectly on the visible list's draw args. */
 uint32_t    trhip_shader_count(void);
 const char* trhip_shader_name(uint32_t index);
 int         trhip_shader_exists(const char* name);

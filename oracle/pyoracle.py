@@ -62,7 +62,9 @@ class FrameDesc(C.Structure):
                 ("hzbMipOffset", C.c_uint64 * MAX_MIPS),
                 ("depth", C.c_void_p), ("depthW", C.c_uint32), ("depthH", C.c_uint32),
                 ("threads", C.c_uint32),
-                ("shardLate", C.c_uint32), ("shardLateBase", C.c_uint32 * 2), ("shardLateTotal", C.c_uint32 * 2)]
+                ("shardLate", C.c_uint32), ("shardLateBase", C.c_uint32 * 2), ("shardLateTotal", C.c_uint32 * 2),
+                ("rasterDepth", C.c_uint32), ("worldToClip", C.c_float * 16),
+                ("vertices", C.c_void_p), ("meshletVertexIds", C.c_void_p), ("meshletTriangles", C.c_void_p)]
 
 
 class FrameOut(C.Structure):
@@ -279,12 +281,34 @@ def occlusion_footprints(centres: np.ndarray, radii: np.ndarray, view: dict, hzb
     return out
 
 
+RawVertexFormat = np.dtype([("m_Position", np.float32, (3,)), ("m_PackedNormal", np.uint32), ("m_TexCoord", np.uint16, (2,))])
+
+
+def raster_depth(consts: np.ndarray, scene: dict, vertices, meshletVertexIds, meshletTriangles, records, visibleList, depth: np.ndarray):
+    """orc_raster_depth: max-merges the depth of the listed visible meshlets into `depth` (float32 [H, W], in place).
+    consts: BasePassConstants (m_WorldToClip, m_OutputResolution, m_NearPlane are read)."""
+    k = np.ascontiguousarray(consts)
+    v = np.ascontiguousarray(vertices, RawVertexFormat)
+    vid = np.ascontiguousarray(meshletVertexIds, np.uint32)
+    tri = np.ascontiguousarray(meshletTriangles, np.uint32)
+    rec = np.ascontiguousarray(records)
+    lst = np.ascontiguousarray(visibleList, np.uint32)
+    assert depth.dtype == np.float32 and depth.flags.c_contiguous
+    assert depth.shape == (int(k["m_OutputResolution"].reshape(-1)[1]), int(k["m_OutputResolution"].reshape(-1)[0]))
+    L = lib()
+    L.orc_raster_depth.argtypes = [C.c_void_p] * 9 + [C.c_uint32, C.c_void_p]
+    L.orc_raster_depth(_p(k), _p(scene["instances"]), _p(scene["meshData"]), _p(scene["meshlets"]), _p(v), _p(vid), _p(tri), _p(rec), _p(lst),
+                       len(lst), _p(depth))
+    return depth
+
+
 class FrameResult:
     pass
 
 
 def frame(scene: dict, view: dict, hzb: HzbTexture, depth: np.ndarray | None, *, cullingFlags=7, forceMeshLOD=-1,
-          freeze=False, maxGroups=65535, threads=1, record_capacity=None, list_capacity=None, shard_late=None) -> FrameResult:
+          freeze=False, maxGroups=65535, threads=1, record_capacity=None, list_capacity=None, shard_late=None,
+          raster=None) -> FrameResult:
     """Run BasePassRenderer::RenderBasePass on the CPU.  `scene`: instances, meshData, meshlets,
     opaqueIds, alphaMaskIds (numpy, wire dtypes).  `view`: worldToView, prevWorldToView, viewToClip,
     nearPlane, renderHeight.  hzb is updated in place (it is the previous frame's on entry)."""
@@ -304,8 +328,16 @@ def frame(scene: dict, view: dict, hzb: HzbTexture, depth: np.ndarray | None, *,
     for i, o in enumerate(hzb.offsets):
         d.hzbMipOffset[i] = o
     if depth is not None:
+        assert raster is None or (depth.dtype == np.float32 and depth.flags.c_contiguous and depth.flags.writeable)
         depth = np.ascontiguousarray(depth, np.float32)
         d.depth, d.depthH, d.depthW = _p(depth), depth.shape[0], depth.shape[1]
+    if raster is not None:
+        w2c, rv, rvid, rtri = raster
+        rv = np.ascontiguousarray(rv, RawVertexFormat)
+        rvid, rtri = np.ascontiguousarray(rvid, np.uint32), np.ascontiguousarray(rtri, np.uint32)
+        d.rasterDepth = 1
+        d.worldToClip[:] = [float(x) for x in np.ascontiguousarray(w2c, np.float32).reshape(16)]
+        d.vertices, d.meshletVertexIds, d.meshletTriangles = _p(rv), _p(rvid), _p(rtri)
     d.threads = int(threads)
     if shard_late is not None:      # multi-GPU checker: ((base_opaque, total_opaque), (base_alpha, total_alpha))
         d.shardLate = 1

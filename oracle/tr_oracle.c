@@ -586,6 +586,85 @@ uint64_t orc_meshlet_cull(const OrcBasePassConstants* k,
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* Depth of the visible meshlets (convention; see tr_oracle.h)                          */
+/* ------------------------------------------------------------------------------------ */
+
+/* mul(float4(p,1), M) incl. the w column: same chain as mul_point per component */
+static inline void mul_point4(const float p[3], const OrcMatrix* M, float o[4])
+{
+    for (int j = 0; j < 4; ++j)
+        o[j] = fmaf(p[2], M->m[2][j], fmaf(p[1], M->m[1][j], p[0] * M->m[0][j])) + M->m[3][j];
+}
+
+/* edge function of (a, b) at p */
+static inline float edge_fn(const float a[2], const float b[2], float px, float py)
+{
+    return fmaf(b[0] - a[0], py - a[1], -((b[1] - a[1]) * (px - a[0])));
+}
+
+void orc_raster_depth(const OrcBasePassConstants* k,
+                      const OrcBasePassInstanceConstants* instances, const OrcMeshData* meshData,
+                      const OrcMeshletData* meshlets, const OrcRawVertexFormat* vertices,
+                      const uint32_t* meshletVertexIds, const uint32_t* meshletTriangles,
+                      const OrcMeshletAmplificationData* records, const uint32_t* visibleList, uint32_t numVisible,
+                      float* depth)
+{
+    const uint32_t W = k->m_OutputResolution[0], H = k->m_OutputResolution[1];
+    const float halfW = 0.5f * (float)W, halfH = 0.5f * (float)H;
+    for (uint32_t v = 0; v < numVisible; ++v) {
+        const uint32_t g = visibleList[v] >> 5, lane = visibleList[v] & 31u;
+        const OrcMeshletAmplificationData* rec = &records[g];                       /* basepass.hlsl:138-142 */
+        const OrcBasePassInstanceConstants* inst = &instances[rec->m_InstanceConstIdx];
+        const uint32_t lodIdx = rec->m_MeshLOD < ORC_MAX_LODS ? rec->m_MeshLOD : ORC_MAX_LODS - 1;
+        const OrcMeshLODData* lod = &meshData[inst->m_MeshDataIdx].m_MeshLODDatas[lodIdx];
+        const OrcMeshletData* ml = &meshlets[lod->m_MeshletDataBufferIdx + rec->m_MeshletGroupOffset + lane];
+        uint32_t nv = ml->m_VertexAndTriangleCount & 0xFFu;                          /* :144-145 */
+        const uint32_t nt = (ml->m_VertexAndTriangleCount >> 8) & 0xFFu;
+        if (nv > 64u) nv = 64u;                                                     /* kMaxMeshletVertices (ShaderInterop.h:19) */
+        float sx[256], sy[256], sd[256];
+        int ok[256];
+        for (uint32_t i = 0; i < nv; ++i) {                                         /* :149-158 */
+            const OrcRawVertexFormat* vin = &vertices[meshletVertexIds[ml->m_MeshletVertexIDsBufferIdx + i]];
+            float wp[3], clip[4];
+            mul_point(vin->m_Position, &inst->m_WorldMatrix, wp);
+            mul_point4(wp, &k->m_WorldToClip, clip);
+            ok[i] = clip[3] > k->m_NearPlane;
+            const float x = clip[0] / clip[3], y = clip[1] / clip[3];
+            sd[i] = clip[2] / clip[3];
+            sx[i] = fmaf(x, halfW, halfW);
+            sy[i] = fmaf(-y, halfH, halfH);
+        }
+        for (uint32_t t = 0; t < nt; ++t) {                                         /* :178-187 */
+            const uint32_t packed = meshletTriangles[ml->m_MeshletIndexIDsBufferIdx + t];
+            const uint32_t ia = packed & 0xFFu, ib = (packed >> 8) & 0xFFu, ic = (packed >> 16) & 0xFFu;
+            if (ia >= nv || ib >= nv || ic >= nv) continue;
+            if (!(ok[ia] && ok[ib] && ok[ic])) continue;
+            const float v0[2] = { sx[ia], sy[ia] }, v1[2] = { sx[ib], sy[ib] }, v2[2] = { sx[ic], sy[ic] };
+            const float d0 = sd[ia], d1 = sd[ib], d2 = sd[ic];
+            const float area = edge_fn(v0, v1, v2[0], v2[1]);
+            if (!(area != 0.0f)) continue;                                          /* degenerate or NaN */
+            const float sgn = area < 0.0f ? -1.0f : 1.0f;
+            const float fminx = fminf(fminf(v0[0], v1[0]), v2[0]), fmaxx = fmaxf(fmaxf(v0[0], v1[0]), v2[0]);
+            const float fminy = fminf(fminf(v0[1], v1[1]), v2[1]), fmaxy = fmaxf(fmaxf(v0[1], v1[1]), v2[1]);
+            if (!(fmaxx >= 0.0f && fmaxy >= 0.0f && fminx <= (float)W && fminy <= (float)H)) continue;   /* off screen or NaN */
+            const int x0 = (int)fmaxf(floorf(fminx), 0.0f), x1 = (int)fminf(ceilf(fmaxx), (float)(W - 1));
+            const int y0 = (int)fmaxf(floorf(fminy), 0.0f), y1 = (int)fminf(ceilf(fmaxy), (float)(H - 1));
+            for (int py = y0; py <= y1; ++py)
+                for (int px = x0; px <= x1; ++px) {
+                    const float cx = (float)px + 0.5f, cy = (float)py + 0.5f;
+                    const float e0 = sgn * edge_fn(v1, v2, cx, cy), e1 = sgn * edge_fn(v2, v0, cx, cy), e2 = sgn * edge_fn(v0, v1, cx, cy);
+                    if (!(e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f)) continue;
+                    const float den = (e0 + e1) + e2;
+                    if (!(den > 0.0f)) continue;
+                    const float d = fmaf(e2, d2, fmaf(e1, d1, e0 * d0)) / den;
+                    float* dst = &depth[(uint64_t)py * W + px];
+                    if (d > *dst) *dst = d;                                         /* GREATER test; NaN never passes */
+                }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* HZB build                                                                            */
 /* ------------------------------------------------------------------------------------ */
 
@@ -780,6 +859,14 @@ static void run_pass(OrcFrameDesc* d, OrcFrameOut* o, int slot, int late, int al
         }
     }
     o->drawArgs[slot][0] = (uint32_t)cur; o->drawArgs[slot][1] = 1; o->drawArgs[slot][2] = 1;
+
+    if (d->rasterDepth) {                                                  /* MS_Main + depth test of the same DispatchMeshIndirect */
+        bk.m_WorldToClip = d->worldToClip;
+        bk.m_OutputResolution[0] = d->depthW; bk.m_OutputResolution[1] = d->depthH;
+        const uint32_t n = cur < o->listCapacity ? (uint32_t)cur : (uint32_t)o->listCapacity;
+        orc_raster_depth(&bk, d->instances, d->meshData, d->meshlets, d->vertices, d->meshletVertexIds, d->meshletTriangles,
+                         o->records[slot], o->visibleList[slot], n, (float*)d->depth);
+    }
 }
 
 void orc_frame(OrcFrameDesc* d, OrcFrameOut* o)
@@ -796,6 +883,9 @@ void orc_frame(OrcFrameDesc* d, OrcFrameOut* o)
     memcpy(hzb.mipOffset, d->hzbMipOffset, sizeof hzb.mipOffset);
 
     for (int s = 0; s < 4; ++s) { o->passRan[s] = 0; o->meshletsTested[s] = 0; memset(o->drawArgs[s], 0, 12); memset(o->dispatchArgs[s], 0, 12); o->validRecords[s] = 0; }
+
+    if (d->rasterDepth)
+        memset((float*)d->depth, 0, sizeof(float) * (size_t)d->depthW * d->depthH);
 
     run_pass(d, o, 0, 0, 0, flags, frustum, &hzb);                          /* :565-566 */
     if (occlusion) {

@@ -196,6 +196,29 @@ uint64_t orc_meshlet_cull(const OrcBasePassConstants* k,
                           uint32_t* visMask,
                           uint32_t* visibleList, uint64_t* listCursor);
 
+/* ShaderInterop.h:278-283 (20 B): what the mesh shader fetches per vertex. */
+typedef struct {
+    float m_Position[3];
+    uint32_t m_PackedNormal;
+    uint16_t m_TexCoord[2];
+} OrcRawVertexFormat;
+
+/* Depth of the visible meshlets of one pass slot: stand-in for MS_Main (basepass.hlsl:124-188: vertex fetch through the
+ * meshlet vertex-id / packed-triangle buffers, position * world * worldToClip) + the fixed-function rasteriser and
+ * depth test, which have no source to restate -> CONVENTION, parity unpinned:
+ *   clip = mulPoint(mulPoint(p, World), WorldToClip) with w = the 4th column's chain; a triangle with a vertex at
+ *   w <= nearPlane is dropped (no near clipping); ndc = clip.xy / w, depth = clip.z / w (reverse-Z, far = 0);
+ *   screen = (ndc.x * 0.5 + 0.5) * W, (-ndc.y * 0.5 + 0.5) * H as fma; samples at pixel centres; a sample is covered
+ *   iff the three edge functions (fma(dx, py, -(dy * px)) form, oriented by the sign of the area) are >= 0 (both
+ *   windings, ties included); depth = (e0 d0 + e1 d1 + e2 d2) / (e0 + e1 + e2) as an fma chain and one division;
+ *   the buffer keeps the maximum (GREATER test, reverse-Z).  depth[] is max-merged in place. */
+void orc_raster_depth(const OrcBasePassConstants* k,
+                      const OrcBasePassInstanceConstants* instances, const OrcMeshData* meshData,
+                      const OrcMeshletData* meshlets, const OrcRawVertexFormat* vertices,
+                      const uint32_t* meshletVertexIds, const uint32_t* meshletTriangles,
+                      const OrcMeshletAmplificationData* records, const uint32_t* visibleList, uint32_t numVisible,
+                      float* depth);
+
 /* minmaxdownsample CS_Main (minmaxdownsample.hlsl:10-35) + 2x2-min mip chain (FidelityFX SPD,
  * FFXHelpers.cpp:36-115; SPD source absent -> convention, parity unpinned). */
 void orc_hzb_build(const float* depth, uint32_t depthW, uint32_t depthH,
@@ -233,6 +256,14 @@ typedef struct {
      * threads = clamp(ceil(shardLateTotal/64)*32 - shardLateBase, 0, own late count). */
     uint32_t shardLate;
     uint32_t shardLateBase[2], shardLateTotal[2];
+    /* rasterDepth != 0: `depth` is an OUTPUT of the frame instead of an input: cleared to 0 (far) at frame
+     * start, and every pass that ran rasterises its visible meshlets into it (orc_raster_depth) before the next
+     * HZB build, as the mesh + pixel stages of the same draw do (basepass.hlsl:124-205). */
+    uint32_t rasterDepth;
+    OrcMatrix worldToClip;      /* BasePassConstants::m_WorldToClip (BasePassRenderers.cpp:447) */
+    const OrcRawVertexFormat* vertices;
+    const uint32_t* meshletVertexIds;
+    const uint32_t* meshletTriangles;
 } OrcFrameDesc;
 
 /* Outputs per pass slot: 0 early-opaque, 1 late-opaque, 2 early-alphamask, 3 late-alphamask. */

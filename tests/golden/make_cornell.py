@@ -38,6 +38,7 @@ def main():
     view = gltf_lite.view_of(cam, (1920, 1080))
     out = dict(instances=scene.instances, meshData=scene.meshData, meshlets=scene.meshlets, opaqueIds=scene.opaqueIds,
                alphaMaskIds=scene.alphaMaskIds, nodes=scene.nodes, primToNode=scene.primToNode,
+               vertices=scene.vertices, meshletVertexIds=scene.meshletVertexIds, meshletTriangles=scene.meshletTriangles,
                camera=np.array([*cam.position, *cam.orientation, cam.yfov, cam.znear, cam.aspect], np.float64))
     for flags in (5, 7):
         inst, ref = cull(scene, view, flags)

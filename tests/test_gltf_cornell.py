@@ -25,7 +25,9 @@ def _fixture():
     scene = gltf_lite.LoadedScene(z["instances"].view(I.BasePassInstanceConstants).reshape(-1), z["meshData"].view(I.MeshData).reshape(-1),
                                   z["meshlets"].view(I.MeshletData).reshape(-1), z["opaqueIds"], z["alphaMaskIds"],
                                   z["nodes"].view(I.NodeLocalTransform).reshape(-1), z["primToNode"], [camera],
-                                  np.zeros(0, np.uint32), np.zeros(0, np.uint32))
+                                  z["vertices"].view(I.RawVertexFormat).reshape(-1) if "vertices" in z.files else np.zeros(0, I.RawVertexFormat),
+                                  z["meshletVertexIds"] if "meshletVertexIds" in z.files else np.zeros(0, np.uint32),
+                                  z["meshletTriangles"] if "meshletTriangles" in z.files else np.zeros(0, np.uint32))
     return z, scene, camera
 
 

@@ -1,0 +1,146 @@
+"""SURVEY.md 8(f) rank 1 on the GPU: "basepass_MS_Main_depth" (csrc/k_raster.hip) against orc_raster_depth, and the
+two-phase frame that builds its HZB from the depth it rasterised itself against pyoracle.frame(raster=...).
+Bit-exact: the depth is a maximum over per-pixel values computed with the same operations, so it does not depend on
+the order the GPU draws the triangles in."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from scene_gen import all_meshlets_visible, write_city_gltf  # noqa: E402
+from toyrenderer_amd import gltf_lite, synth  # noqa: E402
+from toyrenderer_amd import interop as I  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from toyrenderer_amd import rhi
+    d = rhi.Device(0)
+    yield d
+    d.destroy()
+
+
+def _world(oracle, s):
+    inst = s.instances.copy()
+    oracle.update_instance_consts(s.nodes, s.primToNode, inst)
+    sc = dict(s.as_oracle()); sc["instances"] = inst
+    return inst, sc
+
+
+def _gpu_scene(dev, s, inst):
+    from toyrenderer_amd.frame import GpuScene
+    gs = GpuScene(dev, inst, s.meshData, s.meshlets, s.opaqueIds, s.alphaMaskIds)
+    gs.set_geometry(s.vertices, s.meshletVertexIds, s.meshletTriangles)
+    return gs
+
+
+def _consts(view):
+    k = np.zeros(1, I.BasePassConstants)
+    k["m_WorldToClip"] = I.world_to_clip(view.worldToView, view.viewToClip)
+    k["m_NearPlane"] = view.nearPlane
+    k["m_OutputResolution"] = (view.renderW, view.renderH)
+    return k
+
+
+def _raster_everything(dev, oracle, s, view, eye=None):
+    from toyrenderer_amd import rhi
+    from toyrenderer_amd.rhi import CB, SRV, TEX_UAV
+    inst, sc = _world(oracle, s)
+    gs = _gpu_scene(dev, s, inst)
+    rec, lst = all_meshlets_visible(s)
+    k = _consts(view)
+    ref = np.zeros((view.renderH, view.renderW), np.float32)
+    oracle.raster_depth(k, sc, s.vertices, s.meshletVertexIds, s.meshletTriangles, rec, lst, ref)
+    records = dev.buffer_from(rec, "records", min_bytes=12)
+    visible = dev.buffer_from(lst, "visible")
+    args = dev.create_buffer(12, "drawArgs", stride=12, indirect=True)
+    args.upload(np.array([len(lst), 1, 1], np.uint32))
+    depth = dev.create_texture(view.renderW, view.renderH, 1, rhi.FORMAT_R32_FLOAT, "Depth Buffer")
+    cl = dev.create_command_list()
+    try:
+        cl.open()
+        cl.clear_texture_f32(depth, 0.0)
+        cb = cl.constant_buffer(k, "BasePassConstants")
+        cl.dispatch_indirect("basepass_MS_Main_depth",
+                             [CB(0, cb), SRV(0, gs.instances), SRV(1, gs.vertices), SRV(2, gs.meshData), SRV(4, gs.meshlets), SRV(5, gs.meshletVertexIds),
+                              SRV(6, gs.meshletTriangles), SRV(7, records), SRV(9, visible), TEX_UAV(0, depth, 0)], args)
+        cl.close()
+        dev.execute(cl); dev.wait_idle()
+        got = depth.download_mip(0)
+    finally:
+        cl.release(); depth.release(); args.release(); visible.release(); records.release(); gs.release()
+    return got, ref
+
+
+@pytest.mark.parametrize("render", [(1920, 1080), (257, 131)])
+def test_cornell_depth_matches_the_oracle(dev, oracle, render):
+    from test_gltf_cornell import _fixture
+    z, s, camera = _fixture()
+    assert len(s.vertices) and len(s.meshletTriangles), "fixture carries the geometry (tests/golden/make_cornell.py)"
+    view = gltf_lite.view_of(camera, render)
+    got, ref = _raster_everything(dev, oracle, s, view)
+    assert np.count_nonzero(ref) > 0.5 * ref.size, "the box fills most of the screen"
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_generated_scene_depth_matches_the_oracle(dev, oracle, tmp_path):
+    s = gltf_lite.load(write_city_gltf(tmp_path))
+    view = gltf_lite.view_of(s.cameras[0], (1280, 720))
+    got, ref = _raster_everything(dev, oracle, s, view)
+    assert 0.2 < np.count_nonzero(ref) / ref.size < 0.95
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_camera_inside_the_geometry(dev, oracle, tmp_path):
+    """Triangles crossing the near plane and far off-screen vertices: the drop / clamp rules, not a crash."""
+    s = gltf_lite.load(write_city_gltf(tmp_path))
+    cam = s.cameras[0]
+    P = synth.perspective_rh_reverse_z_infinite(cam.yfov, 16 / 9, cam.znear)
+    V = synth.world_to_view((0.3, 0.0, -8.02), (0.0, float(np.sin(0.4)), 0.0, float(np.cos(0.4))))     # inside the wall, turned
+    view = synth.View(V, V.copy(), P, float(np.float32(cam.znear)), 640, 360)
+    got, ref = _raster_everything(dev, oracle, s, view)
+    assert np.count_nonzero(ref) > 0
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("flags", [7, 3])
+def test_two_phase_frames_on_own_depth(dev, oracle, tmp_path, flags):
+    """Four frames of a moving camera, HZB built from the depth the frame rasterised: every list, the depth buffer and
+    the HZB chain equal the oracle's after every frame."""
+    from test_gpu_parity import _compare_frame
+    from toyrenderer_amd.frame import FrameDriver
+    s = gltf_lite.load(write_city_gltf(tmp_path))
+    inst, sc = _world(oracle, s)
+    gs = _gpu_scene(dev, s, inst)
+    cam = s.cameras[0]
+    render = (1280, 720)
+    P = synth.perspective_rh_reverse_z_infinite(cam.yfov, render[0] / render[1], cam.znear)
+    V0 = synth.world_to_view((0.0, 0.0, 0.0), cam.orientation)
+    view = synth.View(V0, V0.copy(), P, float(np.float32(cam.znear)), *render)
+    drv = FrameDriver(dev, gs, view, record_capacity=4096, culling_flags=flags, raster_depth=True)
+    hzb = oracle.HzbTexture(*view.hzb_dims)
+    depth = np.zeros((render[1], render[0]), np.float32)
+    prevV = V0
+    try:
+        late_seen = culled = False
+        for f, eye in enumerate([(0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (0.4, 0.1, -0.3), (0.9, 0.1, -0.5)]):
+            V = synth.world_to_view(eye, cam.orientation)
+            drv.view = view = synth.View(V, prevV, P, float(np.float32(cam.znear)), *render)
+            prevV = V
+            drv.record(); drv.run()
+            got = drv.results()
+            geo = (I.world_to_clip(V, P), s.vertices, s.meshletVertexIds, s.meshletTriangles)
+            ref = oracle.frame(sc, view.as_dict(), hzb, depth, cullingFlags=flags, record_capacity=4096, raster=geo)
+            _compare_frame(got, ref)
+            assert np.array_equal(drv.depth.download_mip(0).view(np.uint32), depth.view(np.uint32)), f"frame {f}: depth differs"
+            assert np.array_equal(drv.hzb.download_chain(), hzb.texels), f"frame {f}: HZB chain differs"
+            late_seen |= bool(ref.lateCount[0] > 0 and ref.drawArgs[1][0] > 0)
+            culled |= bool(f > 0 and ref.drawArgs[0][0] + ref.drawArgs[1][0] < ref.meshletsTested[0] + ref.meshletsTested[1])
+        assert late_seen and culled, "the case must exercise the late pass and cull something"
+    finally:
+        drv.release(); gs.release()

@@ -1,0 +1,147 @@
+"""The oracle's depth rasteriser (orc_raster_depth) and the frame that closes the two-phase loop over it
+(pyoracle.frame(raster=...)).  The rasteriser's rules are this build's convention (parity unpinned: the reference uses
+the fixed-function rasteriser); these tests pin the convention by properties that any correct rasteriser has."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from scene_gen import all_meshlets_visible, write_city_gltf  # noqa: E402
+from toyrenderer_amd import gltf_lite, synth  # noqa: E402
+from toyrenderer_amd import interop as I  # noqa: E402
+
+
+def _consts(view):
+    k = np.zeros(1, I.BasePassConstants)
+    k["m_WorldToClip"] = I.world_to_clip(view.worldToView, view.viewToClip)
+    k["m_NearPlane"] = view.nearPlane
+    k["m_OutputResolution"] = (view.renderW, view.renderH)
+    return k
+
+
+def _one_triangle_scene(tri, world=None):
+    """One instance, one mesh, one meshlet holding one triangle."""
+    inst = np.zeros(1, I.BasePassInstanceConstants)
+    inst["m_WorldMatrix"][0] = np.eye(4, dtype=np.float32) if world is None else world
+    md = np.zeros(1, I.MeshData)
+    md["m_NumLODs"] = 1
+    md["m_MeshLODDatas"]["m_NumMeshlets"][0][0] = 1
+    ml = np.zeros(1, I.MeshletData)
+    ml["m_VertexAndTriangleCount"] = 3 | (1 << 8)
+    v = np.zeros(3, I.RawVertexFormat)
+    v["m_Position"] = np.asarray(tri, np.float32)
+    sc = dict(instances=inst, meshData=md, meshlets=ml)
+    rec = np.zeros(1, I.MeshletAmplificationData)
+    return sc, v, np.arange(3, dtype=np.uint32), np.array([0 | (1 << 8) | (2 << 16)], np.uint32), rec, np.zeros(1, np.uint32)
+
+
+def test_one_triangle_covers_its_pixel_centres_with_exact_plane_depth(oracle):
+    view = synth.make_view(render=(64, 48))
+    z = -5.0
+    tri = [(-1.0, -0.5, z), (1.2, -0.4, z), (0.1, 0.9, z)]
+    sc, v, vid, t, rec, lst = _one_triangle_scene(tri)
+    k = _consts(view)
+    depth = np.zeros((48, 64), np.float32)
+    oracle.raster_depth(k, sc, v, vid, t, rec, lst, depth)
+    # reference coverage in float64 from the projected vertices
+    M = k["m_WorldToClip"][0].astype(np.float64)
+    clip = np.concatenate([np.asarray(tri, np.float64), np.ones((3, 1))], 1) @ M
+    ndc = clip[:, :3] / clip[:, 3:4]
+    sx, sy = (ndc[:, 0] * 0.5 + 0.5) * 64, (-ndc[:, 1] * 0.5 + 0.5) * 48
+    ys, xs = np.mgrid[0:48, 0:64]
+    cx, cy = xs + 0.5, ys + 0.5
+
+    def edge(i, j):
+        return (sx[j] - sx[i]) * (cy - sy[i]) - (sy[j] - sy[i]) * (cx - sx[i])
+    e = np.stack([edge(1, 2), edge(2, 0), edge(0, 1)])
+    s = np.sign(edge(0, 1)[0, 0] * 0 + ((sx[1] - sx[0]) * (sy[2] - sy[0]) - (sy[1] - sy[0]) * (sx[2] - sx[0])))
+    inside = np.all(e * s > 1e-6, 0)
+    outside = np.any(e * s < -1e-6, 0)
+    assert inside.sum() > 100
+    assert np.all(depth[inside] > 0) and np.all(depth[outside] == 0), "coverage = pixel centres inside the triangle"
+    # a triangle at constant view depth has constant depth near/z (reverse-Z, infinite far plane)
+    assert np.allclose(depth[inside], 0.1 / 5.0, rtol=2e-6)
+
+
+def test_winding_and_draw_order_do_not_matter_and_near_crossing_triangles_are_dropped(oracle):
+    view = synth.make_view(render=(96, 64))
+    k = _consts(view)
+    a = [(-1.0, -0.5, -4.0), (1.2, -0.4, -6.0), (0.1, 0.9, -5.0)]
+    sc, v, vid, t, rec, lst = _one_triangle_scene(a)
+    d1 = np.zeros((64, 96), np.float32); oracle.raster_depth(k, sc, v, vid, t, rec, lst, d1)
+    t2 = np.array([0 | (2 << 8) | (1 << 16)], np.uint32)
+    d2 = np.zeros((64, 96), np.float32); oracle.raster_depth(k, sc, v, vid, t2, rec, lst, d2)
+    # both windings rasterise (the reference's PSO culls back faces; the cone test has already done that per meshlet and
+    # this convention keeps the rasteriser conservative).  The interpolation sums in vertex order, so only ~1 ulp apart.
+    assert d1.max() > 0 and np.count_nonzero((d1 > 0) != (d2 > 0)) <= 2 and np.allclose(d1[(d1 > 0) & (d2 > 0)], d2[(d1 > 0) & (d2 > 0)], rtol=1e-6)
+    # a vertex behind the near plane drops the whole triangle (no clipping)
+    b = [(-1.0, -0.5, -4.0), (1.2, -0.4, 0.5), (0.1, 0.9, -5.0)]
+    sc, v, vid, t, rec, lst = _one_triangle_scene(b)
+    d3 = np.zeros((64, 96), np.float32); oracle.raster_depth(k, sc, v, vid, t, rec, lst, d3)
+    assert d3.max() == 0
+    # max-merge: drawing into a buffer that already holds nearer depth leaves it alone
+    d4 = np.full((64, 96), 0.9, np.float32); oracle.raster_depth(k, sc, v, vid, t, rec, lst, d4)
+    assert np.all(d4 == np.float32(0.9))
+
+
+def _load_city(tmp_path, oracle):
+    s = gltf_lite.load(write_city_gltf(tmp_path))
+    inst = s.instances.copy()
+    oracle.update_instance_consts(s.nodes, s.primToNode, inst)
+    sc = dict(s.as_oracle()); sc["instances"] = inst
+    return s, sc
+
+
+def test_rasterised_depth_is_order_independent_on_a_real_scene(tmp_path, oracle):
+    s, sc = _load_city(tmp_path, oracle)
+    view = gltf_lite.view_of(s.cameras[0], (480, 270))
+    k = _consts(view)
+    rec, lst = all_meshlets_visible(s)
+    assert len(lst) == len(s.meshlets) * 0 + sum(int(s.meshData[int(i["m_MeshDataIdx"])]["m_MeshLODDatas"]["m_NumMeshlets"][0]) for i in s.instances)
+    d1 = np.zeros((270, 480), np.float32); oracle.raster_depth(k, sc, s.vertices, s.meshletVertexIds, s.meshletTriangles, rec, lst, d1)
+    rng = np.random.default_rng(0)
+    d2 = np.zeros((270, 480), np.float32); oracle.raster_depth(k, sc, s.vertices, s.meshletVertexIds, s.meshletTriangles, rec, rng.permutation(lst), d2)
+    assert np.array_equal(d1, d2)
+    assert 0.2 < np.count_nonzero(d1) / d1.size < 0.95 and d1.max() < 0.1 / 4.0
+
+
+def test_two_phase_frames_on_own_depth_lose_no_pixel(tmp_path, oracle):
+    """The point of the two-phase scheme: with occlusion culling on, the frame's depth equals the depth of drawing
+    everything the frustum + cone tests keep.  The HZB test is conservative up to fp16 rounding of the pyramid (the HZB
+    stores min depth rounded to NEAREST, Q10), so a handful of pixels may differ; the bound below is a property of the
+    reference's algorithm, not of this restatement."""
+    s, sc = _load_city(tmp_path, oracle)
+    cam = s.cameras[0]
+    render = (640, 360)
+    P = synth.perspective_rh_reverse_z_infinite(cam.yfov, render[0] / render[1], cam.znear)
+    hzb = oracle.HzbTexture(*I.hzb_dims(*render))
+    prevV = None
+    culled_any = False
+    lost = []
+    for f, eye in enumerate([(0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (0.4, 0.1, -0.3), (0.9, 0.1, -0.5)]):
+        V = synth.world_to_view(eye, cam.orientation)
+        view = synth.View(V, V if prevV is None else prevV, P, float(np.float32(cam.znear)), *render)
+        prevV = V
+        w2c = I.world_to_clip(view.worldToView, view.viewToClip)
+        geo = (w2c, s.vertices, s.meshletVertexIds, s.meshletTriangles)
+        depth = np.zeros((render[1], render[0]), np.float32)
+        res = oracle.frame(sc, view.as_dict(), hzb, depth, cullingFlags=7, record_capacity=4096, raster=geo)
+        full = np.zeros_like(depth)
+        oracle.frame(sc, view.as_dict(), oracle.HzbTexture(*I.hzb_dims(*render)), full, cullingFlags=5, record_capacity=4096, raster=geo)
+        drawn = int(res.drawArgs[:, 0].sum())
+        everything = int(oracle.frame(sc, view.as_dict(), oracle.HzbTexture(*I.hzb_dims(*render)), None, cullingFlags=5, record_capacity=4096).drawArgs[:, 0].sum())
+        assert drawn <= everything
+        culled_any |= drawn < everything
+        lost.append(np.count_nonzero(depth != full))
+        if f > 0:
+            assert res.lateCount[0] < len(s.opaqueIds), "the previous frame's HZB lets most instances through the early pass"
+    assert culled_any, "the wall must hide part of the field"
+    # frame 0 starts from a cleared HZB (nothing is occluded); frame 1 repeats the camera: the only losses possible are
+    # the algorithm's own (2x2 footprint at floor(log2) level, fp16 rounding).  Frames 2-3 move the camera: meshlets of
+    # early-pass instances that the PREVIOUS frame's HZB hides are not retested late (basepass.hlsl AS_Main has no
+    # per-meshlet late list), so disocclusion costs some pixels for one frame -- the reference's behaviour, bounded here.
+    print("pixels lost per frame:", lost)
+    assert lost[0] == 0 and lost[1] <= 16 and max(lost[2:]) <= 0.005 * render[0] * render[1]

@@ -47,10 +47,19 @@ class GpuScene:
         self.opaqueIds = dev.buffer_from(np.asarray(opaqueIds, np.uint32), "OpaqueInstanceIDsBuffer", uav=False)
         self.alphaMaskIds = dev.buffer_from(np.asarray(alphaMaskIds, np.uint32), "AlphaMaskInstanceIDsBuffer", uav=False)
         self.numOpaque, self.numAlphaMask = len(opaqueIds), len(alphaMaskIds)
+        self.vertices = self.meshletVertexIds = self.meshletTriangles = None
+
+    def set_geometry(self, vertices, meshletVertexIds, meshletTriangles):
+        """The buffers the mesh shader reads (basepass.hlsl t1, t5, t6): lets the frame rasterise its own depth
+        (FrameDriver(raster_depth=True)) instead of taking a synthetic depth image."""
+        self.vertices = self.dev.buffer_from(np.ascontiguousarray(vertices, I.RawVertexFormat), "GlobalVertexBuffer", uav=False, min_bytes=20)
+        self.meshletVertexIds = self.dev.buffer_from(np.ascontiguousarray(meshletVertexIds, np.uint32), "GlobalMeshletVertexIdxOffsetsBuffer", uav=False)
+        self.meshletTriangles = self.dev.buffer_from(np.ascontiguousarray(meshletTriangles, np.uint32), "GlobalMeshletIndicesBuffer", uav=False)
 
     def release(self):
-        for b in (self.instances, self.meshData, self.meshlets, self.opaqueIds, self.alphaMaskIds):
-            b.release()
+        for b in (self.instances, self.meshData, self.meshlets, self.opaqueIds, self.alphaMaskIds, self.vertices, self.meshletVertexIds, self.meshletTriangles):
+            if b is not None:
+                b.release()
 
 
 class FrameDriver:
@@ -58,11 +67,13 @@ class FrameDriver:
 
     def __init__(self, dev: rhi.Device, scene: GpuScene, view, *, record_capacity: int, list_capacity: int | None = None,
                  culling_flags: int = 7, force_mesh_lod: int = -1, freeze_culling_camera: bool = False, alloc=None,
-                 shard_late=None):
+                 shard_late=None, raster_depth: bool = False):
         """alloc(nbytes, name, stride, indirect) -> rhi.Buffer or None: lets the caller own the memory of the
         output buffers (e.g. torch tensors handed to RCCL, gather.py); None -> device allocation.
         shard_late(hip_stream, late_count_ptr, shard_info_ptr, bucket, phase): multi-GPU hook, called while the
         frame is submitted: phase 0 after each early instance cull, phase 1 before each late one (include/trhost.h)."""
+        self.raster_depth = bool(raster_depth)       # depth = the visible meshlets rasterised ("basepass_MS_Main_depth"), cleared per frame
+        assert not self.raster_depth or scene.vertices is not None, "raster_depth needs GpuScene.set_geometry()"
         self.shard_late = shard_late
         self.shardInfo = [dev.create_buffer(8, f"ShardLateInfo{b}") for b in (0, 1)] if shard_late is not None else None
         self.dev, self.scene, self.view = dev, scene, view
@@ -125,6 +136,7 @@ class FrameDriver:
         k = np.zeros(1, I.BasePassConstants)
         occ = bool(self.flags & 2)
         k["m_WorldToView"] = v.worldToView
+        k["m_WorldToClip"] = I.world_to_clip(v.worldToView, v.viewToClip)
         k["m_Frustum"] = culling_frustum(v.viewToClip)
         k["m_CullingFlags"] = (self.flags & ~4) if alpha_mask else self.flags   # :436-442 (Q8)
         k["m_HZBDimensions"] = (self.hzb_w, self.hzb_h) if occ else (1, 1)
@@ -186,6 +198,10 @@ class FrameDriver:
         if occ:
             bindings.append(TEX_SRV(8, self.hzb))
         cl.dispatch_indirect(f"basepass_AS_Main LATE_CULL={int(late)}", bindings, self.dispatchArgs[slot])   # :497-502
+        if self.raster_depth:                                                            # the mesh + pixel stage of the same draw: depth only
+            b = [CB(0, cb), SRV(0, sc.instances), SRV(1, sc.vertices), SRV(2, sc.meshData), SRV(4, sc.meshlets), SRV(5, sc.meshletVertexIds),
+                 SRV(6, sc.meshletTriangles), SRV(7, self.records[slot]), SRV(9, self.visibleList[slot]), TEX_UAV(0, self.depth, 0)]
+            cl.dispatch_indirect("basepass_MS_Main_depth", b, self.drawArgs[slot])
 
     # ---- BasePassRenderer::GenerateHZB (:505-542) + SPD::Execute (FFXHelpers.cpp:36-115) --------
     def _generate_hzb(self, cl):
@@ -211,6 +227,9 @@ class FrameDriver:
         cl.open()
         occ = bool(self.flags & 2)
         self.ran = [False] * 4
+
+        if self.raster_depth:
+            cl.clear_texture_f32(self.depth, 0.0)                                        # depth cleared to far at the start of the base pass
 
         def do(slot, late, am):
             self.ran[slot] = self._gpu_culling(cl, slot, late, am)

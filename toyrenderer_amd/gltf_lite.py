@@ -50,7 +50,8 @@ class LoadedScene:
     nodes: np.ndarray          # NodeLocalTransform
     primToNode: np.ndarray     # u32 per primitive
     cameras: list
-    meshletVertexIds: np.ndarray   # per meshlet vertex: index into the primitive's vertex array (+ global offset)
+    vertices: np.ndarray           # RawVertexFormat: the global vertex buffer (positions; packed normals when present)
+    meshletVertexIds: np.ndarray   # per meshlet vertex: index into the global vertex buffer
     meshletTriangles: np.ndarray   # packed a | b << 8 | c << 16 (Visual.cpp:396-403)
 
     def as_oracle(self) -> dict:
@@ -180,7 +181,7 @@ def load(path_or_gltf, blobs=None) -> LoadedScene:
 
     materials = g.get("materials", [])
     mesh_prims = []                                   # per glTF mesh: [(meshIdx, alphaMask)]
-    md_rows, ml_rows, mvid, mtri = [], [], [], []
+    md_rows, ml_rows, mvid, mtri, vtx = [], [], [], [], []
     vertex_base = 0
     for mesh in g.get("meshes", []):
         prims = []
@@ -210,6 +211,13 @@ def load(path_or_gltf, blobs=None) -> LoadedScene:
                 mtri.extend((tri[:, 0].astype(np.uint32) | (tri[:, 1].astype(np.uint32) << 8) | (tri[:, 2].astype(np.uint32) << 16)).tolist())
                 ml_rows.append(m)
             mat = materials[prim["material"]] if "material" in prim and prim["material"] < len(materials) else {}
+            vrows = np.zeros(len(pos), I.RawVertexFormat)
+            vrows["m_Position"] = pos
+            if "NORMAL" in prim["attributes"]:                                       # R10G10B10A2: x bits 20-29, y 10-19, z 0-9 (Visual.cpp:440-449)
+                nrm = np.clip(_accessor(g, blobs, prim["attributes"]["NORMAL"]).astype(np.float32), -1, 1)
+                q = np.round((nrm * 0.5 + 0.5) * 1023.0).astype(np.uint32)
+                vrows["m_PackedNormal"] = (q[:, 0] << 20) | (q[:, 1] << 10) | q[:, 2]
+            vtx.append(vrows)
             prims.append((len(md_rows), mat.get("alphaMode", "OPAQUE") == "MASK"))
             md_rows.append(row)
             vertex_base += len(pos)
@@ -267,7 +275,7 @@ def load(path_or_gltf, blobs=None) -> LoadedScene:
         return np.array(rows, dt) if rows else np.zeros(0, dt)
     return LoadedScene(stack(inst_rows, I.BasePassInstanceConstants), stack(md_rows, I.MeshData), stack(ml_rows, I.MeshletData),
                        np.array(opaque, np.uint32), np.array(alpha, np.uint32), nodes, np.array(prim_to_node, np.uint32), cameras,
-                       np.array(mvid, np.uint32), np.array(mtri, np.uint32))
+                       np.concatenate(vtx) if vtx else np.zeros(0, I.RawVertexFormat), np.array(mvid, np.uint32), np.array(mtri, np.uint32))
 
 
 def view_of(camera: Camera, render=(1920, 1080)):

@@ -58,6 +58,26 @@ for _n, _s in SIZES.items():
     assert globals()[_n].itemsize == _s, (_n, globals()[_n].itemsize, _s)
 
 
+RawVertexFormat = np.dtype([("m_Position", np.float32, (3,)), ("m_PackedNormal", np.uint32), ("m_TexCoord", np.uint16, (2,))])   # ShaderInterop.h:278-283
+assert RawVertexFormat.itemsize == 20
+
+
+def world_to_clip(world_to_view, view_to_clip) -> np.ndarray:
+    """m_WorldToClip = WorldToView * ViewToClip in float32, summed left to right without fused multiply-add: the
+    one definition used by every host side of this repo (Python and csrc/host/MathUtilities), so that the oracle
+    and the GPU are handed the same 16 numbers."""
+    a = np.asarray(world_to_view, np.float32).reshape(4, 4)
+    b = np.asarray(view_to_clip, np.float32).reshape(4, 4)
+    out = np.zeros((4, 4), np.float32)
+    for i in range(4):
+        for j in range(4):
+            acc = np.float32(a[i, 0] * b[0, j])
+            for k_ in (1, 2, 3):
+                acc = np.float32(acc + np.float32(a[i, k_] * b[k_, j]))
+            out[i, j] = acc
+    return out
+
+
 def get_next_pow2(x: int) -> int:
     """MathUtilities.h:47-61"""
     if x == 0:
