@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--flags", type=int, default=7, help="culling flags (7 = frustum+occlusion+cone, the headline config)")
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="diagnostic: this single process plays rank 0 of M (its shard of the scene, a 1-rank RCCL group for the exchange); "
+                         "the printed line is NOT a bench result")
     args = ap.parse_args()
 
     # The driver parses ONE JSON line from stdout; RCCL prints its version banner there.  Everything
@@ -138,7 +141,8 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
-    force_gather = bool(os.environ.get("TR_FORCE_GATHER"))     # exercise the RCCL path with a 1-rank group (tests)
+    force_gather = bool(os.environ.get("TR_FORCE_GATHER")) or args.emulate_ranks > 1     # exercise the RCCL path with a 1-rank group (tests)
+    shard_world, shard_rank = (args.emulate_ranks, 0) if args.emulate_ranks > 1 else (world, rank)
     if world > 1 or force_gather:
         import torch.distributed as dist
         if force_gather and "MASTER_ADDR" not in os.environ:
@@ -158,7 +162,7 @@ def main():
     spec = synth.config_spec(args.config)
     view = synth.make_view(eye=(0.0, 0.0, 0.0), prev_eye=(0.05, 0.0, 0.1), prev_yaw=0.002)
     depth = synth.gen_depth(view, 200)
-    i0, i1 = shard_range(spec.num_instances, rank, world)
+    i0, i1 = shard_range(spec.num_instances, shard_rank, shard_world)
     groups_per_instance = (spec.meshlets_lod0 + 31) // 32
     record_cap = (i1 - i0) * groups_per_instance + 1
 
@@ -166,14 +170,14 @@ def main():
     r = host.Renderer(render=(view.renderW, view.renderH), device_index=local_rank, stream=stream,
                       max_groups=record_cap, max_transient_bytes=8 << 30)
     dev = rhi.Device(handle=r.device())
-    (i0, i1), n_local, n_total = build_shard(spec, rank, world, r, threads=min(8, host_threads()))
+    (i0, i1), n_local, n_total = build_shard(spec, shard_rank, shard_world, r, threads=min(8, host_threads()))
     r.set_culling(args.flags)
     r.set_gpu_timers(False)          # the per-renderer timer queries are instrumentation (2 timestamp packets each)
     r.upload_depth(depth)
     gather = None
     if dist is not None:
         # one slot size for all ranks: the largest shard, every instance submitted at LOD 0
-        slot_groups = max(b - a for a, b in (shard_range(spec.num_instances, p, world) for p in range(world))) * groups_per_instance
+        slot_groups = max(b - a for a, b in (shard_range(spec.num_instances, p, shard_world) for p in range(shard_world))) * groups_per_instance
         gather = NativeShardExchange(r, dist, world, rank, slot_groups, pass_slots=(0, 1),
                                   group_capacity=spec.num_instances * groups_per_instance,
                                   overlap=not os.environ.get("TR_NO_OVERLAP"), stage_through_host=backend != "nccl")
@@ -321,6 +325,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         out["lists_digest"] = lists_digest
+        if args.emulate_ranks > 1:
+            out["metric"] = f"DIAGNOSTIC (rank 0 of {args.emulate_ranks} emulated on one GPU) - not a bench result"
         if gather_checked is not None:
             out["gather_checked"] = gather_checked
     sync()

@@ -369,3 +369,39 @@ def test_table_kernel_on_small_and_non_square_hzbs(dev, oracle, render, flags):
                            alpha_mask_fraction=0.1, seed=77)
     got, ref = _run_case(dev, oracle, spec, view, flags=flags, max_groups=1 << 19, depth_prev=d_prev, depth_cur=d_cur, frames=2)
     assert ref.dispatchArgs[0][0] > 1000 and 0 < ref.drawArgs[0][0] < ref.meshletsTested[0]
+
+
+def test_clear_hoisting_and_elision_keep_command_order_semantics(dev):
+    """The back end moves a clear of memory no earlier command uses into the recording's first clear launch and drops
+    a clear of memory that still holds the value (trhip_internal.h); what the commands observe must not change."""
+    a = dev.create_buffer(64, "a"); b = dev.create_buffer(64, "b"); c = dev.create_buffer(64, "c")
+    d = dev.create_buffer(64, "d"); e = dev.create_buffer(64, "e"); f = dev.create_buffer(64, "f")
+    ramp = np.arange(16, dtype=np.uint32) + 100
+    for buf in (a, b, c, d, e, f):
+        buf.upload(np.full(16, 0xDEADBEEF, np.uint32))
+    cl = dev.create_command_list()
+    try:
+        for _ in range(2):                               # the second execution re-records from scratch
+            cl.open()
+            cl.clear_buffer_u32(a, 0)                    # first clear launch of the recording
+            cl.write_buffer(d, ramp)                     # d is used ...
+            cl.copy_buffer(e, d, 64)                     # ... and read before it is cleared: e must get the ramp
+            cl.clear_buffer_u32(c, 5)                    # c: no earlier use -> joins the first launch
+            cl.clear_buffer_u32(d, 7)                    # d: used earlier -> stays in place
+            cl.clear_buffer_u32(a, 0)                    # still 0 -> dropped
+            cl.write_buffer(a, ramp)
+            cl.copy_buffer(f, a, 64)
+            cl.clear_buffer_u32(a, 0)                    # written since -> NOT dropped
+            cl.clear_buffer_u32(b, 9)
+            cl.close()
+            dev.execute(cl); dev.wait_idle()
+            assert np.all(a.download(np.uint32, 16) == 0)
+            assert np.all(b.download(np.uint32, 16) == 9)
+            assert np.all(c.download(np.uint32, 16) == 5)
+            assert np.all(d.download(np.uint32, 16) == 7)
+            assert np.array_equal(e.download(np.uint32, 16), ramp)
+            assert np.array_equal(f.download(np.uint32, 16), ramp)
+    finally:
+        cl.release()
+        for buf in (a, b, c, d, e, f):
+            buf.release()

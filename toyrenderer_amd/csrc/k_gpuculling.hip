@@ -63,7 +63,11 @@ struct InstanceCullArgs
     uint32_t* permHeader;
     uint4* perm;                    // {record index, instance, lod, group offset}: the record itself, in processing order
     uint32_t permCapacity;
+    uint32_t* lateArgsOut;          // early, optional: gpuculling_CS_BuildLateCullIndirectArgs folded into the scan (recordBuildLateArgs)
 };
+
+// What an early recordGPUCulling leaves for a recordBuildLateArgs that follows it immediately (trhip_cmdlist_t::peephole).
+struct EarlyCullNote { InstanceCullArgs a; size_t scanOp; };
 
 __global__ __launch_bounds__(256) void instanceCacheKernel(const BasePassInstanceConstants* instances, uint32_t n,
                                                            const MeshData* meshData, uint32_t numMeshes, InstanceCullCache c)
@@ -301,7 +305,15 @@ __global__ __launch_bounds__(1024) void instanceScanKernel(InstanceCullArgs a)
             a.dispatchArgs[2] = 1;
         }
         if (a.argsWords > 3) a.dispatchArgs[3] = X;           // valid records; the first dropped instance lowers it in C
-        if (!LATE) *a.lateCount = baseLate + (uint32_t)s_carryLS;   // :165
+        if (!LATE) {
+            const uint32_t late = baseLate + (uint32_t)s_carryLS;
+            *a.lateCount = late;                                // :165
+            if (a.lateArgsOut) {                                // gpuculling.hlsl:182-195 (Q1), folded in
+                a.lateArgsOut[0] = (late + 63u) / 64u;
+                a.lateArgsOut[1] = 1;
+                a.lateArgsOut[2] = 1;
+            }
+        }
         // The tile-sorted processing order is published only when every group is emitted (no Q2 drop,
         // pass started from a cleared counter) and fits: then it is a permutation of [0, X).
         a.permHeader[0] = (n >= kMinBinnedEntries && baseX == 0 && X < a.maxGroups && X <= a.permCapacity) ? 1u : 0u;
@@ -490,7 +502,7 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
         a.perm = (uint4*)(a.permHeader + kPermHeaderWords);
         a.permCapacity = a.maxGroups;
     }
-    rc = ctx.cl->recordClearWords(a.tileCount, kNumTiles * kTileReplicas, 0);   // joins the pass's other clears in one launch
+    rc = ctx.cl->recordClearWords(a.tileCount, kNumTiles * kTileReplicas, 0, true);   // scratch of this pass: joins the recording's first clear launch
     if (rc != TRHIP_OK) return rc;
     // The early meshlet cull that follows this pass resolves its HZB lookups through the footprint-min table of
     // this same HZB (k_hzb.hip): bring the table up to date on the side stream while the instance pass runs.
@@ -505,9 +517,11 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
     ctx.emit("scan", [a](hipStream_t s) {
         hipLaunchKernelGGL(instanceScanKernel<LATE>, dim3(1), dim3(1024), 0, s, a);
         return trhip::launchStatus("instanceScanKernel"); });
+    const size_t scanOp = ctx.cl->ops.size() - 1;
     ctx.emit("emit", [a](hipStream_t s) {
         hipLaunchKernelGGL(instanceEmitKernel<LATE>, dim3(a.numBlocks), dim3(kBlock), 0, s, a);
         return trhip::launchStatus("instanceEmitKernel"); });
+    if (!LATE && occlusion) ctx.cl->peephole = { ctx.cl->ops.size() - 1, "gpuculling_early", std::make_shared<EarlyCullNote>(EarlyCullNote{ a, scanOp }) };
     return TRHIP_OK;
 }
 
@@ -521,6 +535,24 @@ int recordBuildLateArgs(trhip::DispatchCtx& ctx)
     TRHIP_REQUIRE(!ctx.indirect && ctx.gx == 1 && ctx.gy == 1 && ctx.gz == 1, "%s: dispatched as 1x1x1", ctx.shaderName);
     const uint32_t* c = (const uint32_t*)count->ptr;
     uint32_t* a = (uint32_t*)args->ptr;
+    // The reference records this dispatch right after the early instance cull that produced the count
+    // (BasePassRenderers.cpp:367-389): then the cull's scan kernel, which writes the count, writes the arguments too.
+    const trhip_cmdlist_t::Peephole ph = ctx.cl->peephole;
+    if (ph.kind && !strcmp(ph.kind, "gpuculling_early") && ph.op != SIZE_MAX && ph.op == ctx.cl->ops.size() - 1) {
+        const EarlyCullNote* note = (const EarlyCullNote*)ph.data.get();
+        if (note->a.lateCount == c && note->scanOp < ctx.cl->ops.size() && ctx.cl->ops[note->scanOp].lane == 0) {
+            InstanceCullArgs fused = note->a;
+            fused.lateArgsOut = a;
+            const size_t scanOp = note->scanOp;
+            ctx.cl->ops[scanOp].fn = [fused](hipStream_t s) {
+                hipLaunchKernelGGL(instanceScanKernel<0>, dim3(1), dim3(1024), 0, s, fused);
+                return trhip::launchStatus("instanceScanKernel"); };
+            // this dispatch's accesses (count read, arguments written) now happen in the scan command
+            for (size_t i = ctx.cl->useMarks.size(); i-- > 0 && ctx.cl->useMarks[i].op >= ctx.cl->ops.size();) ctx.cl->useMarks[i].op = scanOp;
+            ctx.cl->peephole = trhip_cmdlist_t::Peephole();
+            return TRHIP_OK;
+        }
+    }
     ctx.emit("main", [c, a](hipStream_t s) {
         hipLaunchKernelGGL(buildLateCullIndirectArgsKernel, dim3(1), dim3(1), 0, s, c, a);
         return trhip::launchStatus("buildLateCullIndirectArgsKernel"); });

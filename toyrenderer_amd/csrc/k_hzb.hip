@@ -97,6 +97,78 @@ __global__ __launch_bounds__(256) void spdTileKernel(SpdArgs a, uint32_t lastMip
     }
 }
 
+// Depth -> mip 0 -> mips 1..6 of one 64x64 tile in ONE launch: minMaxDownsampleKernel + spdTileKernel when the two
+// dispatches follow each other on the same HZB (recordSPD).  Mip 0 is produced row by row (lane = consecutive x, the
+// access pattern of minMaxDownsampleKernel), stored, and kept in LDS AS STORED (rounded to fp16): the reduction above
+// it reads what a separate SPD pass would read back.
+template <bool MAX>
+__global__ __launch_bounds__(256) void hzbDepthTileKernel(const float* __restrict__ depth, uint32_t W, uint32_t H, SpdArgs a, uint32_t lastMip)
+{
+    __shared__ float s0[64 * 64];
+    __shared__ float s[2][32 * 32];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tx = blockIdx.x, ty = blockIdx.y;
+    _Float16* m0 = a.base + a.mipOffset[0];
+    const uint32_t ow = a.width, oh = a.height;
+    {
+        const uint32_t lx = tid & 63u, x = tx * 64 + lx;
+        const float u = ((float)x + 0.5f) / (float)ow;                                // minmaxdownsample.hlsl:20
+        const float fx = cm::fma_(u, (float)W, -0.5f);
+        int x0 = (int)__builtin_floorf(fx);
+        const int x1 = min(max(x0 + 1, 0), (int)W - 1);
+        x0 = min(max(x0, 0), (int)W - 1);
+#pragma unroll 4
+        for (uint32_t it = 0; it < 16; ++it) {
+            const uint32_t ly = it * 4 + (tid >> 6), y = ty * 64 + ly;
+            const float v = ((float)y + 0.5f) / (float)oh;
+            const float fy = cm::fma_(v, (float)H, -0.5f);
+            int y0 = (int)__builtin_floorf(fy);
+            const int y1 = min(max(y0 + 1, 0), (int)H - 1);
+            y0 = min(max(y0, 0), (int)H - 1);
+            const float p = depth[(uint64_t)y0 * W + x0], q = depth[(uint64_t)y0 * W + x1];
+            const float r = depth[(uint64_t)y1 * W + x0], t = depth[(uint64_t)y1 * W + x1];
+            const _Float16 h = (_Float16)red4<MAX>(p, q, r, t);                       // R16_FLOAT store, RNE (Q10)
+            m0[(uint64_t)y * ow + x] = h;
+            s0[ly * 64 + lx] = (float)h;
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t px = (tid & 15) * 2, py = (tid >> 4) * 2;
+        for (uint32_t dy = 0; dy < 2; ++dy)
+            for (uint32_t dx = 0; dx < 2; ++dx) {
+                const uint32_t ox = px + dx, oy = py + dy;
+                const float v = red4<MAX>(s0[(2 * oy) * 64 + 2 * ox], s0[(2 * oy) * 64 + 2 * ox + 1],
+                                          s0[(2 * oy + 1) * 64 + 2 * ox], s0[(2 * oy + 1) * 64 + 2 * ox + 1]);
+                s[0][oy * 32 + ox] = v;
+                if (lastMip >= 1) {
+                    const uint32_t mw = a.width >> 1;
+                    a.base[a.mipOffset[1] + (uint64_t)(ty * 32 + oy) * mw + tx * 32 + ox] = (_Float16)v;
+                }
+            }
+    }
+    __syncthreads();
+    uint32_t cur = 0, dim = 32;
+    for (uint32_t mip = 2; mip <= 6 && mip <= lastMip; ++mip) {
+        const uint32_t od = dim >> 1;
+        if (tid < od * od) {
+            const uint32_t ox = tid % od, oy = tid / od;
+            const float* p = s[cur];
+            const float v = red4<MAX>(p[(2 * oy) * dim + 2 * ox], p[(2 * oy) * dim + 2 * ox + 1],
+                                      p[(2 * oy + 1) * dim + 2 * ox], p[(2 * oy + 1) * dim + 2 * ox + 1]);
+            s[cur ^ 1][oy * od + ox] = v;
+            const uint32_t mw = a.width >> mip;
+            a.base[a.mipOffset[mip] + (uint64_t)(ty * od + oy) * mw + tx * od + ox] = (_Float16)v;
+        }
+        __syncthreads();
+        cur ^= 1;
+        dim = od;
+    }
+}
+
+// What recordMinMaxDownsample leaves for a recordSPD that follows it immediately (trhip_cmdlist_t::peephole).
+struct MinMaxNote { const float* depth; uint32_t W, H; _Float16* out; uint32_t ow, oh; bool mx; };
+
 // Tail pass: one workgroup, starting from mip `first` (at most 64x64 texels), produces every
 // remaining mip with the clamped 2x2 rule (non-square chains degenerate to 2x1 / 1x2 blocks).
 template <bool MAX>
@@ -193,6 +265,7 @@ int recordMinMaxDownsample(trhip::DispatchCtx& ctx)
         if (mx) hipLaunchKernelGGL(minMaxDownsampleKernel<true>, grid, dim3(256), 0, s, depth, W, H, out, ow, oh);
         else hipLaunchKernelGGL(minMaxDownsampleKernel<false>, grid, dim3(256), 0, s, depth, W, H, out, ow, oh);
         return trhip::launchStatus("minMaxDownsampleKernel"); });
+    ctx.cl->peephole = { ctx.cl->ops.size() - 1, "minmaxdownsample", std::make_shared<MinMaxNote>(MinMaxNote{ depth, W, H, out, ow, oh, mx }) };
     return TRHIP_OK;
 }
 
@@ -213,6 +286,9 @@ int recordSPD(trhip::DispatchCtx& ctx)
         TRHIP_REQUIRE(t == tex && m == i, "%s: UAV u%u must be HZB mip %u (FFXHelpers.cpp:76-81)", ctx.shaderName, 2 + i, i);
     }
     TRHIP_REQUIRE(!ctx.indirect, "%s: dispatched directly", ctx.shaderName);
+    // u0 = the SPD global atomic counter (FFXHelpers.cpp:69): bound for interface fidelity; these kernels order the
+    // tail after the tiles by a second launch and never touch it, so it stays as cleared.
+    if (trhip_buffer_t* counter = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 0)) ctx.cl->forgetUse(counter->ptr, ctx.cl->ops.size());
     const bool mx = ctx.variant == 2;
     SpdArgs a;
     memset(&a, 0, sizeof a);
@@ -223,7 +299,23 @@ int recordSPD(trhip::DispatchCtx& ctx)
 
     uint32_t first = 0;
     const bool tiled = (tex->width % 64 == 0) && (tex->height % 64 == 0);
-    if (tiled) {
+    // The reference's GenerateHZB (BasePassRenderers.cpp:505-542) is minmaxdownsample immediately followed by SPD on
+    // the same texture: when exactly that was recorded, both become one launch in the first command's place.
+    const trhip_cmdlist_t::Peephole ph = ctx.cl->peephole;
+    const MinMaxNote* note = (ph.kind && !strcmp(ph.kind, "minmaxdownsample") && ph.op == ctx.cl->ops.size() - 1 && ph.op != SIZE_MAX) ? (const MinMaxNote*)ph.data.get() : nullptr;
+    const bool fuse = tiled && note && note->out == a.base + a.mipOffset[0] && note->ow == tex->width && note->oh == tex->height && note->mx == mx
+                      && ctx.cl->ops.back().lane == 0;
+    if (fuse) {
+        const MinMaxNote n = *note;
+        const uint32_t lastMip = tex->mips - 1 < 6 ? tex->mips - 1 : 6;
+        ctx.cl->ops.pop_back();
+        ctx.emit("depth_tile", [a, n, lastMip, mx](hipStream_t s) {
+            dim3 grid(a.width / 64, a.height / 64);
+            if (mx) hipLaunchKernelGGL(hzbDepthTileKernel<true>, grid, dim3(256), 0, s, n.depth, n.W, n.H, a, lastMip);
+            else hipLaunchKernelGGL(hzbDepthTileKernel<false>, grid, dim3(256), 0, s, n.depth, n.W, n.H, a, lastMip);
+            return trhip::launchStatus("hzbDepthTileKernel"); });
+        first = lastMip;
+    } else if (tiled) {
         const uint32_t lastMip = tex->mips - 1 < 6 ? tex->mips - 1 : 6;
         ctx.emit("tile", [a, lastMip, mx](hipStream_t s) {
             dim3 grid(a.width / 64, a.height / 64);

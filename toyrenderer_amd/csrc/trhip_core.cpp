@@ -186,6 +186,10 @@ void trhip_cmdlist_t::resetRecording()
     useMarks.clear();
     openClearBatch.reset();
     openClearOp = SIZE_MAX;
+    firstClearBatch.reset();
+    firstClearOp = SIZE_MAX;
+    clearedTo.clear();
+    peephole = Peephole();
     for (ScratchBlock& b : scratch) b.used = 0;
     for (ScratchBlock& b : sideScratch) b.used = 0;
 }
@@ -205,9 +209,15 @@ __global__ __launch_bounds__(256) void multiClearKernel(ClearKernelArgs a)
 }
 }
 
-int trhip_cmdlist_t::recordClearWords(void* ptr, uint64_t words, uint32_t value)
+int trhip_cmdlist_t::recordClearWords(void* ptr, uint64_t words, uint32_t value, bool fresh)
 {
     if (words == 0) return TRHIP_OK;
+    if (fresh && firstClearBatch && firstClearBatch->count < ClearBatch::kMax) {
+        ClearBatch& f = *firstClearBatch;
+        f.ptr[f.count] = ptr; f.words[f.count] = words; f.value[f.count] = value;
+        ++f.count;
+        return TRHIP_OK;
+    }
     if (!(openClearBatch && openClearOp == ops.size() - 1 && openClearBatch->count < ClearBatch::kMax)) {
         openClearBatch = std::make_shared<ClearBatch>();
         std::shared_ptr<ClearBatch> b = openClearBatch;
@@ -224,6 +234,7 @@ int trhip_cmdlist_t::recordClearWords(void* ptr, uint64_t words, uint32_t value)
             return trhip::launchStatus("multiClearKernel"); } });
         ops.back().kind = "clear_buffer";
         openClearOp = ops.size() - 1;
+        if (!firstClearBatch) { firstClearBatch = openClearBatch; firstClearOp = openClearOp; }
     }
     ClearBatch& b = *openClearBatch;
     b.ptr[b.count] = ptr; b.words[b.count] = words; b.value[b.count] = value;
@@ -611,9 +622,13 @@ int trhip_cmd_clear_buffer_u32(trhip_cmdlist cl, trhip_buffer buf, uint32_t valu
     if (!buf) return fail(TRHIP_ERR_INVALID, "clear_buffer: null buffer");
     if (!buf->ptr) return fail(TRHIP_ERR_STATE, "clear_buffer(%s): no memory bound", buf->name.c_str());
     if (buf->byteSize % 4) return fail(TRHIP_ERR_INVALID, "clear_buffer(%s): size not a multiple of 4", buf->name.c_str());
+    if (cl->stillClearedTo(buf->ptr, value)) return TRHIP_OK;      // cleared to it earlier in this recording, no command has written it since
+    const bool hoist = !cl->usedSoFar(buf->ptr) && cl->firstClearBatch && cl->firstClearBatch->count < trhip_cmdlist_t::ClearBatch::kMax;
     const bool merges = cl->openClearBatch && cl->openClearOp == cl->ops.size() - 1 && cl->openClearBatch->count < trhip_cmdlist_t::ClearBatch::kMax;
-    cl->hold(buf, true, merges ? cl->openClearOp : cl->ops.size());
-    return cl->recordClearWords(buf->ptr, buf->byteSize / 4, value);
+    cl->hold(buf, true, hoist ? cl->firstClearOp : merges ? cl->openClearOp : cl->ops.size());
+    int rc = cl->recordClearWords(buf->ptr, buf->byteSize / 4, value, hoist);
+    if (rc == TRHIP_OK) cl->clearedTo[buf->ptr] = { value, cl->useMarks.size() };
+    return rc;
 }
 
 int trhip_cmd_clear_texture_f32(trhip_cmdlist cl, trhip_texture tex, float value)

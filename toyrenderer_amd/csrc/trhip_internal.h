@@ -178,16 +178,48 @@ struct trhip_cmdlist_t
 
     // Consecutive buffer clears are issued as ONE kernel launch (a frame has ~11 clears of a few bytes
     // each; a launch costs ~5 us on both sides of the queue).
-    struct ClearBatch { static constexpr uint32_t kMax = 8; void* ptr[kMax]; uint64_t words[kMax]; uint32_t value[kMax]; uint32_t count = 0; };
+    struct ClearBatch { static constexpr uint32_t kMax = 16; void* ptr[kMax]; uint64_t words[kMax]; uint32_t value[kMax]; uint32_t count = 0; };
     std::shared_ptr<ClearBatch> openClearBatch;    // batch of the LAST op in `ops`, if that op is a clear
     size_t openClearOp = SIZE_MAX;
-    int recordClearWords(void* ptr, uint64_t words, uint32_t value);
+    // A clear of memory that no earlier command of this recording uses joins the FIRST clear launch of the recording
+    // (it is equivalent there, and off the chain of dependent small launches later in the frame); a clear of memory
+    // that still holds the value (cleared to it earlier in this recording, not written since) is dropped.
+    std::shared_ptr<ClearBatch> firstClearBatch;
+    size_t firstClearOp = SIZE_MAX;
+    struct ClearedTo { uint32_t value; size_t marks; };       // marks: useMarks.size() right after the clear was noted
+    std::unordered_map<const void*, ClearedTo> clearedTo;     // whole allocations, by base pointer
+    bool stillClearedTo(const void* ptr, uint32_t value) const
+    {
+        auto it = clearedTo.find(ptr);
+        if (it == clearedTo.end() || it->second.value != value) return false;
+        for (size_t i = it->second.marks; i < useMarks.size(); ++i)
+            if (useMarks[i].ptr == ptr && useMarks[i].write) return false;
+        return true;
+    }
+    // fresh: the caller guarantees that no earlier command of this recording uses the memory (scratch just allocated)
+    int recordClearWords(void* ptr, uint64_t words, uint32_t value, bool fresh = false);
+    bool usedSoFar(const void* ptr) const { for (const UseMark& m : useMarks) if (m.ptr == ptr) return true; return false; }
 
     // Which allocations each command uses (recorded by hold()): checked against the side stream's runs
     // when the list is executed.
     struct UseMark { size_t op; const void* ptr; bool write; std::atomic<uint64_t>* version; };
     std::vector<UseMark> useMarks;
-    void use(const void* ptr, size_t op, bool write, std::atomic<uint64_t>* version = nullptr) { if (ptr) useMarks.push_back({ op, ptr, write, version }); }
+    void use(const void* ptr, size_t op, bool write, std::atomic<uint64_t>* version = nullptr)
+    {
+        if (!ptr) return;
+        useMarks.push_back({ op, ptr, write, version });
+    }
+    // the command being recorded turned out not to access `ptr` (bound for interface fidelity only): forget its marks
+    void forgetUse(const void* ptr, size_t op)
+    {
+        for (size_t i = useMarks.size(); i-- > 0 && useMarks[i].op >= op;)
+            if (useMarks[i].op == op && useMarks[i].ptr == ptr) useMarks.erase(useMarks.begin() + (ptrdiff_t)i);
+    }
+
+    // Peephole between two consecutive commands of one recording: a record function may leave a note about the command
+    // it just emitted; the next record function may replace that command by a fused one (same command index, so the
+    // use marks of both stay attached to it).  Cleared by any other command.
+    struct Peephole { size_t op = SIZE_MAX; const char* kind = nullptr; std::shared_ptr<void> data; } peephole;
 
     void* scratchAlloc(size_t bytes);       // device memory valid until the list is re-opened/released
     void* scratchAllocSide(size_t bytes);   // same, from an arena only side-stream ops use (they are in order among themselves)
