@@ -92,6 +92,20 @@ def test_c3_bench_workload_100m_meshlets(oracle):
         _properties(got, s)
 
 
+def test_c3_one_rank_share_of_eight(oracle):
+    """configs[3] as ONE of 8 ranks sees it: 97 656 instances x 128 unique meshlets (12.5 M), record capacity
+    390 625 < 2^19 -- the single-launch list compaction (191 tiles chained by look-back), main-stream list build,
+    texel-path occlusion lookups; three frames so that the HZB feedback and the late pass are in steady state."""
+    spec = synth.config_spec("C3r")
+    cap = spec.num_instances * ((spec.meshlets_lod0 + 31) // 32) + 1
+    assert cap < (1 << 19)
+    got, ref = _run(oracle, spec, frames=3, cap=cap)
+    assert int(ref.meshletsTested[0]) > 5_000_000 and 0 < int(ref.drawArgs[0][0]) < int(ref.meshletsTested[0])
+    assert int(ref.drawArgs[1][0]) > 0, "late pass draws something"
+    for s in (0, 1):
+        _properties(got, s)
+
+
 def test_c2_without_the_side_stream():
     """The same C2 frames with the back end's side stream switched off (TRHIP_NO_SIDE_STREAM=1: list build and
     footprint-table rebuild run in order on the main stream) -- the overlap machinery must not be what makes

@@ -519,6 +519,103 @@ __global__ __launch_bounds__(kBlock) void visExpandKernel(MeshletCullArgs a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Single-launch ordered compaction for SMALL passes (record capacity < 2^19: one rank's share of a sharded scene, real
+// assets): count, scan and expand of the three kernels above in one, so that the list costs one link of the frame's
+// chain of dependent launches instead of three (a link is ~6 us whatever it does; DESIGN.md "Launch chain").
+// A workgroup takes tiles of kCompactTile consecutive groups in TICKET order; a tile publishes its count as soon as
+// it has it and then sums the counts of ALL its predecessors (at most 255: one thread each, one round trip).  A tile
+// only ever waits for tiles with smaller tickets, which are held by workgroups already running: no deadlock whatever
+// the grid size.  A status word carries flag and count in ONE 64-bit relaxed agent-scope atomic, so no fence is
+// needed (the data a tile writes is consumed by later launches only).  The spin is bounded: on expiry the tile poisons its prefix (bit 48),
+// the poison travels through the sums to the last tile, which then writes 0xFFFFFFFF draw arguments (never seen in
+// practice; a wrong list fails parity, a hang would take the GPU down).
+constexpr uint32_t kCompactTile = 2048;                 // groups per tile
+constexpr uint32_t kCompactThreads = 1024;              // 2 groups per thread; 16 waves keep the expansion's LDS/store latency covered
+constexpr uint32_t kCompactWaves = kCompactThreads / 64;
+constexpr uint32_t kCompactMaxTiles = (1u << 19) / kCompactTile;
+constexpr uint32_t kStatusStride = 16;                  // one status word per 128-byte line: 255 waiters per word, all tiles at once
+constexpr uint64_t kFlagA = 1ull << 62, kFlagMask = 3ull << 62, kPoison = 1ull << 48;
+
+__global__ __launch_bounds__(kCompactThreads) void visCompactKernel(MeshletCullArgs a, unsigned long long* status, uint32_t* ticket)
+{
+    __shared__ uint32_t s_mask[kCompactTile];
+    __shared__ uint32_t s_off[kCompactTile];
+    __shared__ uint32_t s_waveTot[kCompactWaves];
+    __shared__ uint32_t s_tile;
+    __shared__ unsigned long long s_pre[kCompactMaxTiles / 64u];
+    const uint32_t G = groupCount(a);
+    const uint32_t numTiles = (G + kCompactTile - 1) / kCompactTile;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (;;) {
+        if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const uint32_t tile = s_tile;
+        if (tile >= numTiles) {
+            if (tile == 0 && tid == 0) { a.drawArgs[0] = 0; a.drawArgs[1] = 1; a.drawArgs[2] = 1; }    // empty pass
+            return;
+        }
+        // ---- masks of the tile -> LDS; thread t owns groups 2t, 2t+1 of the tile -----------------------------------
+        const uint32_t g0 = tile * kCompactTile;
+        const uint32_t b = g0 + tid * 2u;
+        uint32_t m0 = 0, m1 = 0;
+        if (b + 2u <= G) { const uint2 v = *reinterpret_cast<const uint2*>(a.visMask + b); m0 = v.x; m1 = v.y; }
+        else if (b < G) m0 = a.visMask[b];
+        const uint32_t c0 = (uint32_t)__popc(m0), mine = c0 + (uint32_t)__popc(m1);
+        const uint32_t inc = waveInclusiveScan(mine, lane);
+        if (lane == 63) s_waveTot[wave] = inc;
+        __syncthreads();
+        uint32_t pre = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kCompactWaves; ++w) { const uint32_t x = s_waveTot[w]; if (w < wave) pre += x; total += x; }
+        const uint32_t exc = pre + inc - mine;
+        *reinterpret_cast<uint2*>(&s_mask[tid * 2u]) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(&s_off[tid * 2u]) = make_uint2(exc, exc + c0);
+        // ---- prefix of the tile: the counts of ALL its predecessors, read in one parallel round trip (at most
+        // kCompactMaxTiles - 1 = 255 of them: thread j waits for tile j's count) -------------------------------------
+        if (tid == 0) __hip_atomic_store(&status[tile * kStatusStride], kFlagA | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave < kCompactMaxTiles / 64u) {
+            unsigned long long v = 0;
+            if (tid < tile) {
+                uint32_t spins = 0;
+                for (;;) {
+                    v = __hip_atomic_load(&status[tid * kStatusStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v & kFlagMask) { v &= ~kFlagMask; break; }
+                    if (++spins > (1u << 22)) { v = kPoison; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+            if (lane == 0) s_pre[wave] = v;
+        }
+        __syncthreads();
+        unsigned long long base = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kCompactMaxTiles / 64u; ++w) base += s_pre[w];
+        if (tid == 0 && tile == numTiles - 1) {                                      // the last tile knows the total
+            const unsigned long long all = base + total;
+            const bool bad = (all >> 40) != 0ull;                                     // poisoned by a timed-out wait
+            a.drawArgs[0] = bad ? 0xFFFFFFFFu : (uint32_t)all;                        // basepass.hlsl:120-121 summed over groups
+            a.drawArgs[1] = bad ? 0xFFFFFFFFu : 1u;
+            a.drawArgs[2] = bad ? 0xFFFFFFFFu : 1u;
+        }
+        // ---- expansion: one thread per (group, lane) slot, canonical order ------------------------------------------
+        const uint32_t groupsHere = G - g0 < kCompactTile ? G - g0 : kCompactTile;
+#pragma unroll 4
+        for (uint32_t slot = tid; slot < groupsHere * 32u; slot += kCompactThreads) {
+            const uint32_t g = slot >> 5, sub = slot & 31u;
+            const uint32_t mask = s_mask[g];
+            if (mask & (1u << sub)) {
+                const unsigned long long pos = base + s_off[g] + (uint32_t)__popc(mask & ((1u << sub) - 1u));
+                if (pos < a.listCapacity) a.visibleList[pos] = ((g0 + g) << 5) | sub;
+            }
+        }
+        __syncthreads();                                                             // LDS is reused by the next tile
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Multi-GPU exchange (not in the reference: single GPU, GraphicRHI.cpp:165).
 // A rank ships its pass slots in COMPACT form -- the 12-byte record and the 4-byte lane mask of every
@@ -674,6 +771,24 @@ void emitListBuild(const trhip::DispatchCtx& ctx, const MeshletCullArgs& a, cons
         if (side) ctx.emitSide(name.c_str(), std::move(fn), { { argsBase, false }, { a.visMask, false }, { a.visibleList, true }, { a.drawArgs, true } });
         else ctx.emit(name.c_str(), std::move(fn));
     };
+    if (!side && a.recordCapacity <= kCompactMaxTiles * kCompactTile) {
+        // small pass: one launch (visCompactKernel); status words + ticket are scratch of this command, zeroed by the
+        // recording's first clear launch
+        const uint32_t tiles = (a.recordCapacity + kCompactTile - 1) / kCompactTile;
+        const size_t words = (size_t)kCompactMaxTiles * kStatusStride * 2 + 4;
+        uint32_t* mem = (uint32_t*)ctx.scratch(words * 4);
+        if (mem && ctx.cl->recordClearWords(mem, words, 0, true) == TRHIP_OK) {
+            unsigned long long* status = (unsigned long long*)mem;
+            uint32_t* ticket = mem + kCompactMaxTiles * kStatusStride * 2;
+            uint32_t grid = ctx.computeUnits();               // one 1024-thread workgroup per CU
+            if (grid > tiles) grid = tiles;
+            if (grid == 0) grid = 1;
+            emit(std::string(prefix) + "compact", [a, status, ticket, grid](hipStream_t s) {
+                hipLaunchKernelGGL(visCompactKernel, dim3(grid), dim3(kCompactThreads), 0, s, a, status, ticket);
+                return trhip::launchStatus("visCompactKernel"); });
+            return;
+        }
+    }
     const uint32_t needBlocks = (a.maxBatches + kWaves - 1) / kWaves;
     uint32_t gridSmall = ctx.computeUnits() * 8u;      // count / expand: light kernels, one wave per 64 groups
     if (gridSmall > needBlocks) gridSmall = needBlocks;

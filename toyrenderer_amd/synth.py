@@ -266,6 +266,8 @@ def config_spec(name: str) -> SceneSpec:
         return SceneSpec(num_meshes=976_562, num_instances=976_562, meshlets_lod0=128, max_lods=1, unique=True)
     if name == "C3e":  # 1/8 of C3: the per-GPU share of the 8-GPU run (overhead proxy on one GPU)
         return SceneSpec(num_meshes=97_656, num_instances=97_656, meshlets_lod0=128, max_lods=1, unique=True)
+    if name == "C3r":  # one rank's share of C3 on 8 GPUs: 97 656 x 128 = 12.5 M meshlets, 390 625 groups (< 2^19: the small-pass code paths)
+        return SceneSpec(num_meshes=97_656, num_instances=97_656, meshlets_lod0=128, max_lods=1, unique=True)
     if name == "C3s":  # 1/64 of C3 for quick GPU parity runs
         return SceneSpec(num_meshes=12_208, num_instances=12_208, meshlets_lod0=128, max_lods=1, unique=True)
     raise KeyError(name)
