@@ -50,6 +50,14 @@ int  trhost_set_gpu_timers(int enable);
 
 /* Depth image the next frames' GenerateHZB will consume (stand-in for the rasteriser). */
 int  trhost_upload_depth(const float* depth, uint32_t width, uint32_t height);
+/* Instead of the stand-in: the frame rasterises the depth of its own visible meshlets ("basepass_MS_Main_depth", the
+ * compute replacement of MS_Main + depth test, basepass.hlsl:124-188) after every cull pass, from the buffers the mesh
+ * shader reads (SceneLoading.cpp:1016-1088): RawVertexFormat vertices (20 B), meshlet vertex ids, packed meshlet
+ * triangles.  trhost_download_depth: the depth buffer of the last frame (float32, render resolution), after wait_idle. */
+int  trhost_load_geometry(const void* vertices, uint64_t num_vertices, const uint32_t* meshlet_vertex_ids, uint64_t num_vertex_ids,
+                          const uint32_t* meshlet_triangles, uint64_t num_triangles);
+int  trhost_set_raster_depth(int enable);
+int  trhost_download_depth(float* depth, uint64_t bytes);
 int  trhost_upload_hzb_mip(uint32_t mip, const uint16_t* texels, uint64_t bytes);
 int  trhost_download_hzb_mip(uint32_t mip, uint16_t* texels, uint64_t bytes);
 int  trhost_hzb_info(uint32_t* width, uint32_t* height, uint32_t* mips);

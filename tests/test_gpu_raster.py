@@ -144,3 +144,41 @@ def test_two_phase_frames_on_own_depth(dev, oracle, tmp_path, flags):
         assert late_seen and culled, "the case must exercise the late pass and cull something"
     finally:
         drv.release(); gs.release()
+
+
+def test_drop_in_path_renders_its_own_depth(oracle, tmp_path):
+    """The same loop through the C++ host mirror (RenderGraph / GBufferRenderer over the C ABI): node transforms on the
+    GPU, cull, depth of the visible meshlets, HZB -- four frames, moving camera, everything equal to the oracle."""
+    from test_gpu_parity import _compare_frame
+    from toyrenderer_amd import host
+    s = gltf_lite.load(write_city_gltf(tmp_path))
+    inst, sc = _world(oracle, s)
+    cam = s.cameras[0]
+    render = (1280, 720)
+    P = synth.perspective_rh_reverse_z_infinite(cam.yfov, render[0] / render[1], cam.znear)
+    hzb = oracle.HzbTexture(*I.hzb_dims(*render))
+    depth = np.zeros((render[1], render[0]), np.float32)
+    r = host.Renderer(render=render, max_groups=4096)
+    try:
+        r.load_scene(s.instances, s.meshData, s.meshlets, s.opaqueIds, s.alphaMaskIds)
+        r.load_nodes(s.nodes, s.primToNode)
+        r.load_geometry(s.vertices, s.meshletVertexIds, s.meshletTriangles)
+        r.set_raster_depth(True)
+        r.set_culling(7)
+        prevV = synth.world_to_view((0.0, 0.0, 0.0), cam.orientation)
+        for f, eye in enumerate([(0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (0.4, 0.1, -0.3), (0.9, 0.1, -0.5)]):
+            V = synth.world_to_view(eye, cam.orientation)
+            view = synth.View(V, prevV, P, float(np.float32(cam.znear)), *render)
+            prevV = V
+            r.set_node_transforms(s.nodes)
+            r.set_camera(view)
+            r.frame()
+            got = r.results()
+            geo = (I.world_to_clip(V, P), s.vertices, s.meshletVertexIds, s.meshletTriangles)
+            ref = oracle.frame(sc, view.as_dict(), hzb, depth, cullingFlags=7, record_capacity=4096, maxGroups=4096, raster=geo)
+            _compare_frame(got, ref)
+            assert np.array_equal(r.download_depth().view(np.uint32), depth.view(np.uint32)), f"frame {f}: depth differs"
+            assert np.array_equal(r.download_hzb(), hzb.texels), f"frame {f}: HZB chain differs"
+        assert np.count_nonzero(depth) > 0.2 * depth.size
+    finally:
+        r.shutdown()

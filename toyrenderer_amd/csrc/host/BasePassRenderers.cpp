@@ -124,6 +124,7 @@ public:
     };
     PassOutputs m_Outputs[kNumPassSlots];
     nvrhi::BufferHandle m_LastLateCullInstanceCountBuffer, m_LastLateCullDispatchIndirectArgsBuffer;
+    nvrhi::TextureHandle m_CurrentDepthBuffer, m_LastDepthBuffer;     // depth attachment of the pass being recorded / of the last frame (read-back)
 
 protected:
     RenderGraph::ResourceHandle m_LateCullDispatchIndirectArgsRDGBufferHandle;
@@ -392,6 +393,33 @@ public:
         computePassParams.m_IndirectArgsBuffer = meshletDispatchArgumentsBuffer;
         g_Graphic.AddComputePass(computePassParams);
 
+        if (g_Scene->m_bRasterDepth) {
+            // The mesh + depth stages of the same DispatchMeshIndirect (basepass.hlsl:124-188, PSO :481-495), depth only:
+            // one wave per visible meshlet, dispatched on the draw arguments the cull just wrote.
+            check(g_Graphic.m_GlobalVertexBuffer && m_CurrentDepthBuffer);
+            basePassConstants.m_WorldToClip = MultiplyNoFMA(g_Scene->m_View.m_CullingWorldToView, g_Scene->m_View.m_ViewToClip);   // :447
+            nvrhi::BufferHandle rasterConstants = g_Graphic.CreateConstantBuffer(commandList, basePassConstants);
+            nvrhi::BindingSetDesc rasterBindings;
+            rasterBindings.bindings = {
+                nvrhi::BindingSetItem::ConstantBuffer(0, rasterConstants),
+                nvrhi::BindingSetItem::StructuredBuffer_SRV(0, g_Scene->m_InstanceConstsBuffer),
+                nvrhi::BindingSetItem::StructuredBuffer_SRV(1, g_Graphic.m_GlobalVertexBuffer),
+                nvrhi::BindingSetItem::StructuredBuffer_SRV(2, g_Graphic.m_GlobalMeshDataBuffer),
+                nvrhi::BindingSetItem::StructuredBuffer_SRV(4, g_Graphic.m_GlobalMeshletDataBuffer),
+                nvrhi::BindingSetItem::StructuredBuffer_SRV(5, g_Graphic.m_GlobalMeshletVertexOffsetsBuffer),
+                nvrhi::BindingSetItem::StructuredBuffer_SRV(6, g_Graphic.m_GlobalMeshletIndicesBuffer),
+                nvrhi::BindingSetItem::StructuredBuffer_SRV(7, meshletAmplificationDataBuffer),
+                nvrhi::BindingSetItem::StructuredBuffer_SRV(9, visibleListBuffer),
+                nvrhi::BindingSetItem::Texture_UAV(0, m_CurrentDepthBuffer),
+            };
+            Graphic::ComputePassParams rasterPass;
+            rasterPass.m_CommandList = commandList;
+            rasterPass.m_ShaderName = "basepass_MS_Main_depth";
+            rasterPass.m_BindingSetDesc = rasterBindings;
+            rasterPass.m_IndirectArgsBuffer = visibleDrawArgsBuffer;
+            g_Graphic.AddComputePass(rasterPass);
+        }
+
         PassOutputs& out = m_Outputs[slot];
         out.m_bRan = true;
         out.m_MeshletAmplificationDataBuffer = meshletAmplificationDataBuffer;
@@ -452,12 +480,17 @@ public:
         frustumY = Normalize(frustumY);
         m_CullingFrustum = Vector4{ frustumX.x, frustumX.z, frustumY.y, frustumY.z };
 
+        m_CurrentDepthBuffer = params.m_DepthBuffer;
+        m_LastDepthBuffer = params.m_DepthBuffer;
+        if (g_Scene->m_bRasterDepth)                                                                 // the base pass starts from a cleared depth buffer
+            commandList->clearTextureFloat(params.m_DepthBuffer, nvrhi::AllSubresources, nvrhi::Color{ GraphicConstants::kFarDepth });
+
         GPUCulling(commandList, renderGraph, kEarlyOpaque, false /* bLateCull */, false /* bAlphaMaskPrimitives */);          // :565-566
         RenderInstances(commandList, renderGraph, kEarlyOpaque, false, false);
 
         if (m_bDoOcclusionCulling) {                                                                 // :568-581
             // stand-in for the rasteriser: the frame's depth image arrives here
-            if (g_Scene->m_SyntheticDepth) commandList->copyTexture(params.m_DepthBuffer, g_Scene->m_SyntheticDepth);
+            if (g_Scene->m_SyntheticDepth && !g_Scene->m_bRasterDepth) commandList->copyTexture(params.m_DepthBuffer, g_Scene->m_SyntheticDepth);
             GenerateHZB(commandList, renderGraph, params);
 
             GPUCulling(commandList, renderGraph, kLateOpaque, true, false);
@@ -520,6 +553,7 @@ public:
             desc.format = GraphicConstants::kDepthStencilFormat;
             desc.debugName = "Depth Buffer";
             desc.isRenderTarget = true;
+            desc.isUAV = true;                     // this build: the compute rasteriser writes depth through a UAV
             desc.setClearValue(nvrhi::Color{ GraphicConstants::kFarDepth });
             desc.initialState = nvrhi::ResourceStates::DepthRead;
             renderGraph.CreateTransientResource(g_DepthStencilBufferRDGTextureHandle, desc);
@@ -555,12 +589,15 @@ bool GetVisibilityPassBuffers(uint32_t slot, VisibilityPassBuffers* out)
     return true;
 }
 
+nvrhi::TextureHandle GetLastDepthBuffer() { return static_cast<GBufferRenderer*>(g_GBufferRenderer)->m_LastDepthBuffer; }
+
 void ReleaseVisibilityPassBuffers()
 {
     GBufferRenderer* r = static_cast<GBufferRenderer*>(g_GBufferRenderer);
     for (auto& o : r->m_Outputs) o = BasePassRenderer::PassOutputs{};
     r->m_LastLateCullInstanceCountBuffer = nullptr;
     r->m_LastLateCullDispatchIndirectArgsBuffer = nullptr;
+    r->m_CurrentDepthBuffer = nullptr; r->m_LastDepthBuffer = nullptr;
     for (ShardLateCall& c : g_ShardLateCalls) c = ShardLateCall{};
     SetShardLateExchange(nullptr, nullptr);
 }

@@ -77,6 +77,7 @@ void Graphic::Shutdown()
     m_CommonResources.reset();
     m_GlobalMeshDataBuffer = nullptr;
     m_GlobalMeshletDataBuffer = nullptr;
+    m_GlobalVertexBuffer = nullptr; m_GlobalMeshletVertexOffsetsBuffer = nullptr; m_GlobalMeshletIndicesBuffer = nullptr;
     m_PendingCommandLists.clear();
     m_FreeCommandLists.clear();
     m_AllCommandLists.clear();

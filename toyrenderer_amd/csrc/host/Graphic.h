@@ -86,6 +86,8 @@ public:
     // Graphic.h:137-143 (only the buffers on the path)
     nvrhi::BufferHandle m_GlobalMeshDataBuffer;
     nvrhi::BufferHandle m_GlobalMeshletDataBuffer;
+    // what the mesh shader reads (basepass.hlsl t1, t5, t6): only needed when the frame rasterises its own depth
+    nvrhi::BufferHandle m_GlobalVertexBuffer, m_GlobalMeshletVertexOffsetsBuffer, m_GlobalMeshletIndicesBuffer;
 
     Vector2U m_RenderResolution{ 0, 0 };
     uint32_t m_FrameCounter = 0;

@@ -32,6 +32,21 @@ inline Matrix Transpose(const Matrix& m)
     return t;
 }
 
+// Matrix product a * b in float32, every element summed left to right with separate multiplies and adds (the build
+// is -ffp-contract=off): the ONE definition of m_WorldToClip = WorldToView * ViewToClip on every host side of this
+// repo (toyrenderer_amd/interop.py world_to_clip), so that the oracle and the GPU receive the same 16 numbers.
+inline Matrix MultiplyNoFMA(const Matrix& a, const Matrix& b)
+{
+    Matrix r;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float acc = a.m[i][0] * b.m[0][j];
+            for (int k = 1; k < 4; ++k) { const float p = a.m[i][k] * b.m[k][j]; acc = acc + p; }
+            r.m[i][j] = acc;
+        }
+    return r;
+}
+
 // Vector4::Normalize (SimpleMath.inl:1129-1135 -> XMVector4Normalize).  DirectXMath is absent; the
 // build's convention is v / sqrt(dot4) with the dot product as an FMA chain (DESIGN.md "Arithmetic").
 inline Vector4 Normalize(const Vector4& v)

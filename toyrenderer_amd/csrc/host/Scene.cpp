@@ -74,6 +74,26 @@ void Scene::LoadFromArrays(const void* instances, uint32_t numInstances, const v
     upload(m_AlphaMaskInstanceIDsBuffer, alphaMaskIds, (uint64_t)numAlphaMask * 4);
 }
 
+void Scene::LoadGeometry(const void* vertices, uint64_t numVertices, const uint32_t* meshletVertexIds, uint64_t numVertexIds,
+                         const uint32_t* meshletTriangles, uint64_t numTriangles)
+{
+    // UploadGlobalMeshBuffers (SceneLoading.cpp:1016-1088): the vertex / meshlet-vertex-id / meshlet-triangle buffers
+    nvrhi::DeviceHandle device = g_Graphic.m_NVRHIDevice;
+    auto make = [&](const char* name, const void* src, uint64_t bytes, uint32_t stride) {
+        nvrhi::BufferDesc d;
+        d.byteSize = bytes ? bytes : stride;
+        d.structStride = stride;
+        d.debugName = name;
+        d.initialState = nvrhi::ResourceStates::ShaderResource;
+        nvrhi::BufferHandle b = device->createBuffer(d);
+        if (bytes) nvrhi::throwIfFailed(trhip_buffer_upload(b->native(), 0, src, bytes), "Scene geometry upload");
+        return b;
+    };
+    g_Graphic.m_GlobalVertexBuffer = make("GlobalVertexBuffer", vertices, numVertices * 20u, 20u);                       // RawVertexFormat (ShaderInterop.h:278-283)
+    g_Graphic.m_GlobalMeshletVertexOffsetsBuffer = make("GlobalMeshletVertexOffsetsBuffer", meshletVertexIds, numVertexIds * 4u, 4u);
+    g_Graphic.m_GlobalMeshletIndicesBuffer = make("GlobalMeshletIndicesBuffer", meshletTriangles, numTriangles * 4u, 4u);
+}
+
 void Scene::LoadNodes(const void* nodes, uint32_t numNodes, const uint32_t* primitiveToNode)
 {
     // UpdateInstanceConstsRenderer::CreateNodeTransformsBuffer (BasePassRenderers.cpp:64-104)

@@ -78,6 +78,11 @@ public:
     // stand-in for the rasteriser's output (RenderInstances' pixel work is out of scope): the depth
     // image that GenerateHZB consumes is copied from here into the transient depth buffer.
     nvrhi::TextureHandle m_SyntheticDepth;
+    // Instead of the stand-in: every pass rasterises the depth of its visible meshlets ("basepass_MS_Main_depth", the
+    // compute replacement of MS_Main + depth test) into the depth buffer, cleared at the start of the base pass.
+    bool m_bRasterDepth = false;
+    void LoadGeometry(const void* vertices, uint64_t numVertices, const uint32_t* meshletVertexIds, uint64_t numVertexIds,
+                      const uint32_t* meshletTriangles, uint64_t numTriangles);
 
     std::shared_ptr<RenderGraph> m_RenderGraph;
     tf::Executor m_Executor{ 4 };                    // Engine.cpp:19,110-116 (default 12 workers)

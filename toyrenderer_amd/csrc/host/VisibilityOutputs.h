@@ -25,6 +25,9 @@ void ReleaseVisibilityPassBuffers();
 using ShardLateFn = void (*)(void* user, void* hipStream, void* lateCount, void* shardInfo, int bucket, int phase);
 void SetShardLateExchange(ShardLateFn fn, void* user);
 
+// Depth attachment of the last recorded base pass (read-back for tests; null before the first frame).
+nvrhi::TextureHandle GetLastDepthBuffer();
+
 // Native per-frame driver of the multi-GPU exchange (ShardExchange.cpp; C facade in trhost.h).
 struct trhost_exchange_desc;
 void ShardExchangeCreate(const trhost_exchange_desc& desc);

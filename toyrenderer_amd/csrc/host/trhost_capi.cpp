@@ -79,6 +79,32 @@ int trhost_upload_meshlets(uint64_t first_meshlet, const void* meshlets, uint64_
     });
 }
 
+int trhost_load_geometry(const void* vertices, uint64_t num_vertices, const uint32_t* meshlet_vertex_ids, uint64_t num_vertex_ids,
+                         const uint32_t* meshlet_triangles, uint64_t num_triangles)
+{
+    return guarded([&] {
+        check(g_Scene && (vertices || !num_vertices) && (meshlet_vertex_ids || !num_vertex_ids) && (meshlet_triangles || !num_triangles));
+        g_Scene->LoadGeometry(vertices, num_vertices, meshlet_vertex_ids, num_vertex_ids, meshlet_triangles, num_triangles);
+    });
+}
+
+int trhost_set_raster_depth(int enable)
+{
+    return guarded([&] {
+        check(!enable || g_Graphic.m_GlobalVertexBuffer);      // trhost_load_geometry first
+        g_Scene->m_bRasterDepth = enable != 0;
+    });
+}
+
+int trhost_download_depth(float* depth, uint64_t bytes)
+{
+    return guarded([&] {
+        nvrhi::TextureHandle t = GetLastDepthBuffer();
+        check(t);
+        nvrhi::throwIfFailed(trhip_texture_download(t->native(), 0, depth, bytes), "trhost_download_depth");
+    });
+}
+
 int trhost_load_nodes(const void* node_local_transforms, uint32_t num_nodes, const uint32_t* primitive_to_node)
 {
     return guarded([&] { g_Scene->LoadNodes(node_local_transforms, num_nodes, primitive_to_node); });

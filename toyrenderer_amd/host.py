@@ -21,7 +21,7 @@ HOST_SYMBOLS = [
     "trhost_pass_buffers", "trhost_instance_buffer", "trhost_device", "trhost_render_graph_stats", "trhost_renderer_times",
     "trhost_heap_sim", "trhost_set_shard_late_exchange", "trhost_set_gpu_timers",
     "trhost_rccl_allgather", "trhost_exchange_create", "trhost_exchange_run", "trhost_exchange_wait", "trhost_exchange_outputs",
-    "trhost_exchange_destroy",
+    "trhost_exchange_destroy", "trhost_load_geometry", "trhost_set_raster_depth", "trhost_download_depth",
 ]
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)   # trhost_allgather_fn
@@ -68,6 +68,9 @@ def load() -> C.CDLL:
     L.trhost_set_culling.argtypes = [C.c_int] * 5
     L.trhost_set_limits.argtypes = [u32, u64]
     L.trhost_upload_depth.argtypes = [vp, u32, u32]
+    L.trhost_load_geometry.argtypes = [vp, u64, vp, u64, vp, u64]
+    L.trhost_set_raster_depth.argtypes = [C.c_int]
+    L.trhost_download_depth.argtypes = [vp, u64]
     L.trhost_upload_hzb_mip.argtypes = [u32, vp, u64]
     L.trhost_download_hzb_mip.argtypes = [u32, vp, u64]
     L.trhost_hzb_info.argtypes = [C.POINTER(u32)] * 3
@@ -160,6 +163,23 @@ class Renderer:
     def upload_depth(self, depth):
         d = np.ascontiguousarray(depth, np.float32)
         _check(load().trhost_upload_depth(d.ctypes.data, d.shape[1], d.shape[0]))
+
+    def load_geometry(self, vertices, meshlet_vertex_ids, meshlet_triangles):
+        """The buffers the mesh shader reads (RawVertexFormat vertices, meshlet vertex ids, packed meshlet triangles)."""
+        from . import interop as I
+        v = np.ascontiguousarray(vertices, I.RawVertexFormat)
+        vid, tri = np.ascontiguousarray(meshlet_vertex_ids, np.uint32), np.ascontiguousarray(meshlet_triangles, np.uint32)
+        _check(load().trhost_load_geometry(v.ctypes.data, len(v), vid.ctypes.data, len(vid), tri.ctypes.data, len(tri)))
+
+    def set_raster_depth(self, on: bool = True):
+        """The frame rasterises the depth of its own visible meshlets instead of taking the uploaded depth image."""
+        _check(load().trhost_set_raster_depth(int(on)))
+
+    def download_depth(self) -> np.ndarray:
+        self.wait_idle()
+        d = np.empty((self.render[1], self.render[0]), np.float32)
+        _check(load().trhost_download_depth(d.ctypes.data, d.nbytes))
+        return d
 
     def upload_hzb(self, texels, offsets):
         for k in range(self.hzb_mips):
