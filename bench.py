@@ -112,8 +112,8 @@ def cpu_baseline(spec: synth.SceneSpec, view, depth, sample_instances: int, thre
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="C3")
     ap.add_argument("--cpu-sample-instances", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
