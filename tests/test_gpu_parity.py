@@ -179,9 +179,10 @@ def test_cone_unorm_all_byte_values(dev, oracle):
         drv.release(); gs.release()
 
 
-@pytest.mark.parametrize("render", [(100, 40), (640, 360), (1920, 1080), (3840, 2160), (2560, 1440)])
+@pytest.mark.parametrize("render", [(100, 40), (640, 360), (1920, 1080), (3840, 2160), (2560, 1440), (2048, 64), (48, 3000)])
 def test_hzb_build(dev, oracle, render):
-    """minmaxdownsample + SPD replacement vs orc_hzb_build, incl. a non-tiled (<64) and non-square chain."""
+    """minmaxdownsample + SPD replacement vs orc_hzb_build, incl. a non-tiled (<64) and non-square chain, and chains the
+    64x64 tiling does not fit (1024x32, 32x2048: one launch per mip until the tail kernel takes over)."""
     from toyrenderer_amd.frame import FrameDriver, GpuScene
     view = synth.make_view(render=render)
     rng = np.random.default_rng(render[0])
@@ -405,3 +406,36 @@ def test_clear_hoisting_and_elision_keep_command_order_semantics(dev):
         cl.release()
         for buf in (a, b, c, d, e, f):
             buf.release()
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_randomised_small_scene_sweep(dev, oracle, block):
+    """48 random configurations (scene size from 1 instance to ~6000 groups, ragged meshlet counts, 1-8 LODs, alpha-mask
+    share, culling flags, forced LOD, group capacity below / at / above what the frame needs (Q2), odd and non-square
+    render sizes, 1-2 frames): every output word and the HZB chain against the oracle.  Shakes the boundaries the named
+    cases do not sit on (list tiles of exactly 2048 groups, one-group passes, empty late lists, ...)."""
+    renders = [(640, 360), (100, 40), (1280, 720), (333, 517), (64, 64), (1920, 1080), (2048, 64)]
+    for case in range(block * 12, block * 12 + 12):
+        rng = np.random.default_rng(1000 + case)
+        n_inst = int(rng.choice([1, 2, 31, 32, 33, 64, 255, 500, 1024, 2048, 3000]))
+        m0 = int(rng.choice([1, 31, 32, 33, 64, 70, 128, 200]))
+        spec = synth.SceneSpec(num_meshes=int(rng.integers(1, 40)), num_instances=n_inst, meshlets_lod0=m0,
+                               jitter_meshlets=bool(rng.integers(0, 2)), max_lods=int(rng.integers(1, 9)),
+                               alpha_mask_fraction=float(rng.choice([0.0, 0.0, 0.2, 1.0])), seed=5000 + case,
+                               z_near=float(rng.choice([2.0, 5.0, 20.0])), z_far=float(rng.choice([40.0, 200.0])),
+                               box_x=float(rng.choice([10.0, 100.0])), box_y=float(rng.choice([6.0, 56.0])))
+        render = renders[int(rng.integers(0, len(renders)))]
+        view = synth.make_view(eye=tuple(rng.uniform(-0.5, 0.5, 3)), yaw=float(rng.uniform(-0.05, 0.05)),
+                               prev_eye=tuple(rng.uniform(-0.5, 0.5, 3)), prev_yaw=float(rng.uniform(-0.05, 0.05)), render=render)
+        flags = int(rng.integers(0, 8))
+        forced = int(rng.choice([-1, -1, -1, 0, 2, 7]))
+        need = n_inst * ((2 * m0 + 31) // 32) + 1
+        cap = int(rng.choice([65535, need, max(1, need // 3), 2048, 4096]))
+        cap = min(cap, 65535)
+        d_prev = synth.gen_depth(view, num_occluders=int(rng.integers(0, 80)), seed=case, scale=3.0) if rng.integers(0, 4) else None
+        d_cur = synth.gen_depth(view, num_occluders=int(rng.integers(0, 80)), seed=case + 500, scale=3.0)
+        try:
+            _run_case(dev, oracle, spec, view, flags=flags, forced=forced, max_groups=cap, depth_prev=d_prev, depth_cur=d_cur,
+                      frames=int(rng.integers(1, 3)))
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: {spec} render={render} flags={flags} forced={forced} cap={cap}: {e}") from e

@@ -166,6 +166,23 @@ __global__ __launch_bounds__(256) void hzbDepthTileKernel(const float* __restric
     }
 }
 
+// One mip from the one below it, a thread per texel, the tail kernel's clamped 2x2 rule: the general path for chains the
+// 64x64 tiling does not fit (a dimension below 64 while the mip is still larger than 64x64 texels, e.g. the 1024x32
+// HZB of a 2048x64 render).  One launch per mip until the tail kernel can take over.
+template <bool MAX>
+__global__ __launch_bounds__(256) void spdMipKernel(SpdArgs a, uint32_t mip)
+{
+    const uint32_t pw = (a.width >> (mip - 1)) ? (a.width >> (mip - 1)) : 1u, ph = (a.height >> (mip - 1)) ? (a.height >> (mip - 1)) : 1u;
+    const uint32_t mw = (a.width >> mip) ? (a.width >> mip) : 1u, mh = (a.height >> mip) ? (a.height >> mip) : 1u;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= mw * mh) return;
+    const uint32_t x = i % mw, y = i / mw;
+    const uint32_t x0 = min(2 * x, pw - 1), x1 = min(2 * x + 1, pw - 1);
+    const uint32_t y0 = min(2 * y, ph - 1), y1 = min(2 * y + 1, ph - 1);
+    const _Float16* p = a.base + a.mipOffset[mip - 1];
+    a.base[a.mipOffset[mip] + i] = (_Float16)red4<MAX>((float)p[y0 * pw + x0], (float)p[y0 * pw + x1], (float)p[y1 * pw + x0], (float)p[y1 * pw + x1]);
+}
+
 // What recordMinMaxDownsample leaves for a recordSPD that follows it immediately (trhip_cmdlist_t::peephole).
 struct MinMaxNote { const float* depth; uint32_t W, H; _Float16* out; uint32_t ow, oh; bool mx; };
 
@@ -324,9 +341,15 @@ int recordSPD(trhip::DispatchCtx& ctx)
             return trhip::launchStatus("spdTileKernel"); });
         first = lastMip;
     }
-    TRHIP_REQUIRE((uint64_t)tex->mipW(first) * tex->mipH(first) <= 64 * 64,
-                  "%s: HZB %ux%u: mip %u is larger than 64x64 texels (dimensions must be multiples of 64 or at most 64)",
-                  ctx.shaderName, tex->width, tex->height, first);
+    while ((uint64_t)tex->mipW(first) * tex->mipH(first) > 64 * 64 && first + 1 < tex->mips) {     // untiled chain: mip by mip
+        const uint32_t mip = first + 1;
+        const uint32_t texels = tex->mipW(mip) * tex->mipH(mip);
+        ctx.emit("mip", [a, mip, texels, mx](hipStream_t s) {
+            if (mx) hipLaunchKernelGGL(spdMipKernel<true>, dim3((texels + 255u) / 256u), dim3(256), 0, s, a, mip);
+            else hipLaunchKernelGGL(spdMipKernel<false>, dim3((texels + 255u) / 256u), dim3(256), 0, s, a, mip);
+            return trhip::launchStatus("spdMipKernel"); });
+        first = mip;
+    }
     if (first + 1 < tex->mips) {
         ctx.emit("tail", [a, first, mx](hipStream_t s) {
             if (mx) hipLaunchKernelGGL(spdTailKernel<true>, dim3(1), dim3(1024), 0, s, a, first);
