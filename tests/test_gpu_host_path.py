@@ -223,3 +223,50 @@ def test_ranks_sharing_one_gpu_equal_one_rank(world):
     assert d2["n_gpus"] == world and d2["config"]["meshlets_tested_per_frame"] == d1["config"]["meshlets_tested_per_frame"]
     assert d2["config"]["visible_per_frame"] == d1["config"]["visible_per_frame"]
     assert d2["lists_digest"] == d1["lists_digest"], "multi-rank whole-scene lists differ from the 1-rank lists"
+
+
+@pytest.mark.parametrize("block", range(2))
+def test_randomised_sweep_through_the_host_mirror(oracle, block):
+    """24 random configurations through Graphic / RenderGraph / GBufferRenderer (one Renderer per case: initialise,
+    load, 1-3 frames, shut down): scene sizes from 1 instance up, alpha-mask-only and opaque-only scenes, all flag
+    combinations, forced LODs, group capacities below what the frame needs, odd render sizes, freeze-culling-camera."""
+    renders = [(640, 360), (100, 40), (1280, 720), (333, 517), (64, 64), (2048, 64)]
+    for case in range(block * 12, block * 12 + 12):
+        rng = np.random.default_rng(7000 + case)
+        n_inst = int(rng.choice([1, 2, 33, 64, 255, 1024, 3000]))
+        m0 = int(rng.choice([1, 31, 33, 64, 128, 200]))
+        spec = synth.SceneSpec(num_meshes=int(rng.integers(1, 30)), num_instances=n_inst, meshlets_lod0=m0,
+                               jitter_meshlets=bool(rng.integers(0, 2)), max_lods=int(rng.integers(1, 9)),
+                               alpha_mask_fraction=float(rng.choice([0.0, 0.2, 1.0])), seed=9000 + case,
+                               z_near=float(rng.choice([2.0, 5.0, 20.0])), z_far=float(rng.choice([40.0, 200.0])),
+                               box_x=float(rng.choice([10.0, 100.0])), box_y=float(rng.choice([6.0, 56.0])))
+        render = renders[int(rng.integers(0, len(renders)))]
+        view = synth.make_view(eye=tuple(rng.uniform(-0.5, 0.5, 3)), yaw=float(rng.uniform(-0.05, 0.05)),
+                               prev_eye=tuple(rng.uniform(-0.5, 0.5, 3)), prev_yaw=float(rng.uniform(-0.05, 0.05)), render=render)
+        flags = int(rng.integers(0, 8))
+        forced = int(rng.choice([-1, -1, 0, 3]))
+        freeze = bool(rng.integers(0, 5) == 0)
+        need = n_inst * ((2 * m0 + 31) // 32) + 1
+        cap = min(int(rng.choice([65535, need, max(1, need // 3), 2048])), 65535)
+        scene = synth.make_scene(spec)
+        d_cur = synth.gen_depth(view, num_occluders=int(rng.integers(0, 80)), seed=case + 500, scale=3.0)
+        hzb = oracle.HzbTexture(*view.hzb_dims)
+        hzb.build_from_depth(synth.gen_depth(view, num_occluders=int(rng.integers(0, 80)), seed=case, scale=3.0))
+        try:
+            with _Ctx(render, max_groups=cap) as r:
+                r.load_scene(scene.instances, scene.meshData, scene.meshlets, scene.opaqueIds, scene.alphaMaskIds)
+                r.upload_hzb(hzb.texels, hzb.offsets)
+                r.upload_depth(d_cur)
+                for frame in range(int(rng.integers(1, 4))):
+                    fz = freeze and frame > 0         # the culling camera is frozen at the view of the last unfrozen frame (Scene.cpp:139-144)
+                    r.set_culling(flags, freeze=fz, force_mesh_lod=forced)
+                    r.set_camera(view)
+                    r.frame()
+                    got = r.results()
+                    ref = oracle.frame(scene.as_oracle(), view.as_dict(), hzb, d_cur, cullingFlags=flags, forceMeshLOD=forced, freeze=fz,
+                                       maxGroups=cap, record_capacity=cap)
+                    _compare(got, ref)
+                    if flags & 2:
+                        assert np.array_equal(r.download_hzb(), hzb.texels), "HZB chain"
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: {spec} render={render} flags={flags} forced={forced} freeze={freeze} cap={cap}: {e}") from e

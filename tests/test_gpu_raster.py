@@ -182,3 +182,69 @@ def test_drop_in_path_renders_its_own_depth(oracle, tmp_path):
         assert np.count_nonzero(depth) > 0.2 * depth.size
     finally:
         r.shutdown()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_triangle_soup_with_hostile_vertices(dev, oracle, seed):
+    """Random meshlets whose vertices include points behind the camera, on the near plane, far off screen, at 1e30,
+    infinities and NaNs, degenerate and sub-pixel triangles, triangle indices past the meshlet's vertex count: the
+    rules of the convention (drop / clamp / never pass the depth test), bit-exact, and no out-of-range access."""
+    from toyrenderer_amd import rhi
+    rng = np.random.default_rng(seed)
+    n_meshlets = 40
+    view = synth.make_view(render=(320, 200))
+    verts, vids, tris, meshlets = [], [], [], np.zeros(n_meshlets, I.MeshletData)
+    for m in range(n_meshlets):
+        nv, nt = int(rng.integers(3, 65)), int(rng.integers(1, 97))
+        base = len(verts)
+        p = np.stack([rng.uniform(-6, 6, nv), rng.uniform(-4, 4, nv), rng.uniform(-30, 2, nv)], 1)
+        kind = rng.integers(0, 12, nv)
+        p[kind == 0] *= 1e30
+        p[kind == 1, 2] = -0.1                       # exactly on the near plane
+        p[kind == 2, 0] = np.inf
+        p[kind == 3, 1] = np.nan
+        p[kind == 4] = p[0]                          # coincident vertices -> degenerate triangles
+        verts += [tuple(x) for x in p.astype(np.float32)]
+        meshlets[m]["m_MeshletVertexIDsBufferIdx"] = len(vids)
+        vids += list(range(base, base + nv))
+        meshlets[m]["m_MeshletIndexIDsBufferIdx"] = len(tris)
+        hi = nv + (4 if m % 5 == 0 else 0)           # some indices point past the vertex count
+        idx = rng.integers(0, hi, (nt, 3))
+        tris += [int(a | (b << 8) | (c << 16)) for a, b, c in idx]
+        meshlets[m]["m_VertexAndTriangleCount"] = nv | (nt << 8)
+    v = np.zeros(len(verts), I.RawVertexFormat); v["m_Position"] = np.array(verts, np.float32)
+    inst = np.zeros(2, I.BasePassInstanceConstants)
+    inst["m_WorldMatrix"][0] = np.eye(4, dtype=np.float32)
+    inst["m_WorldMatrix"][1] = np.diag([0.5, 2.0, 1.0, 1.0]).astype(np.float32); inst["m_WorldMatrix"][1][3, :3] = (1.0, -0.5, -3.0)
+    md = np.zeros(1, I.MeshData); md["m_NumLODs"] = 1; md["m_MeshLODDatas"]["m_NumMeshlets"][0][0] = n_meshlets
+    sc = dict(instances=inst, meshData=md, meshlets=meshlets)
+    rec = np.zeros(4, I.MeshletAmplificationData)
+    rec["m_InstanceConstIdx"] = [0, 0, 1, 1]; rec["m_MeshletGroupOffset"] = [0, 32, 0, 32]
+    lst = np.array([(g << 5) | l for g in range(4) for l in range(32 if g % 2 == 0 else n_meshlets - 32)], np.uint32)
+    lst = rng.permutation(lst)
+    k = _consts(view)
+    ref = np.zeros((200, 320), np.float32)
+    oracle.raster_depth(k, sc, v, np.array(vids, np.uint32), np.array(tris, np.uint32), rec, lst, ref)
+    assert np.count_nonzero(ref) > 1000 and np.all(np.isfinite(ref[ref > 0]) | np.isinf(ref[ref > 0]))
+    from toyrenderer_amd.rhi import CB, SRV, TEX_UAV
+    bufs = [dev.buffer_from(inst, "inst", uav=False), dev.buffer_from(v, "v", uav=False), dev.buffer_from(md, "md", uav=False),
+            dev.buffer_from(meshlets, "ml", uav=False), dev.buffer_from(np.array(vids, np.uint32), "vid", uav=False),
+            dev.buffer_from(np.array(tris, np.uint32), "tri", uav=False), dev.buffer_from(rec, "rec"), dev.buffer_from(lst, "lst")]
+    args = dev.create_buffer(12, "drawArgs", stride=12, indirect=True)
+    args.upload(np.array([len(lst), 1, 1], np.uint32))
+    depth = dev.create_texture(320, 200, 1, rhi.FORMAT_R32_FLOAT, "Depth Buffer")
+    cl = dev.create_command_list()
+    try:
+        cl.open()
+        cl.clear_texture_f32(depth, 0.0)
+        cb = cl.constant_buffer(k, "BasePassConstants")
+        cl.dispatch_indirect("basepass_MS_Main_depth", [CB(0, cb), SRV(0, bufs[0]), SRV(1, bufs[1]), SRV(2, bufs[2]), SRV(4, bufs[3]), SRV(5, bufs[4]),
+                                                        SRV(6, bufs[5]), SRV(7, bufs[6]), SRV(9, bufs[7]), TEX_UAV(0, depth, 0)], args)
+        cl.close()
+        dev.execute(cl); dev.wait_idle()
+        got = depth.download_mip(0)
+    finally:
+        cl.release(); depth.release(); args.release()
+        for b in bufs:
+            b.release()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
