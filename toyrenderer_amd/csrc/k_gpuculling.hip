@@ -117,7 +117,10 @@ constexpr uint32_t kTilesPerAxis = 32;
 constexpr uint32_t kNumTiles = kTilesPerAxis * kTilesPerAxis;
 constexpr uint32_t kTileReplicas = 32;            // counters are replicated (blockIdx % 32) to spread the atomics
 constexpr uint32_t kPermHeaderWords = 64;
-constexpr uint32_t kMinBinnedEntries = 4096;      // below this many list entries the processing order is left alone (device-side test)
+#ifndef TR_MIN_BINNED
+#define TR_MIN_BINNED 4096
+#endif
+constexpr uint32_t kMinBinnedEntries = TR_MIN_BINNED;      // below this many list entries the processing order is left alone (device-side test)
 
 // Which 1/32 x 1/32 screen tile the instance's centre projects to.  Scheduling heuristic only
 // (approximate reciprocal, no exactness requirement): it never influences an output value.
