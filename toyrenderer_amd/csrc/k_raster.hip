@@ -10,9 +10,13 @@
 // with one fma chain and one division, atomic max on the float bits (depth > 0, so unsigned order = float order).  The
 // result is a maximum, so it does not depend on the order the triangles are drawn in: bit-exact against the oracle.
 //
-// One wave per visible meshlet: lanes transform the (<= 64) vertices into the wave's LDS slice, then the wave walks the
-// triangles one after the other, 64 pixels of the bounding box per pass.  Sized for correctness first; the bound is
-// the bounding-box area, not HBM.
+// Two launches.  "main": one wave per visible meshlet -- lanes transform the (<= 64) vertices into the wave's LDS
+// slice, then the wave walks the triangles one after the other, 64 pixels of the bounding box per pass; a triangle whose
+// box exceeds kSmallBox pixels is not drawn there but appended to a queue (screen positions, depths, box).  "tiles": one
+// workgroup per 64x64-pixel screen tile collects the queued triangles that touch it and rasterises them into an LDS copy
+// of the tile, 4096 pixels at a time, then merges the tile into the depth buffer.  Without the second launch a dozen
+// waves walked the 10^4-pixel boxes of a near wall while the chip idled (3.2 ms per pass at 3840x2160,
+// tools/raster_time.py).  Every pixel value is computed by the same operations whichever launch produces it.
 #include "cull_math.hip.h"
 #include "trhip_internal.h"
 
@@ -23,6 +27,21 @@ namespace
 
 constexpr uint32_t kBlock = 256;
 constexpr uint32_t kWaves = kBlock / 64;
+constexpr uint32_t kSmallBox = 1024;            // pixels: larger bounding boxes go to the tile pass
+constexpr uint32_t kTile = 64;                  // pixels per side
+constexpr uint32_t kQueueCapacity = 1u << 20;   // 48 MB; beyond it triangles are drawn in place (slow, still exact)
+constexpr uint32_t kTileList = 1024;            // queued triangles a tile handles per round
+
+struct BigTriangle                              // 48 bytes
+{
+    float x0, y0, d0, x1, y1, d1, x2, y2, d2, sgn;
+    uint32_t boxX, boxY;                        // x0 | x1 << 16, y0 | y1 << 16 (inclusive pixel bounds)
+};
+
+__device__ __forceinline__ float edgeFn(float ax, float ay, float bx, float by, float px, float py)
+{
+    return cm::fma_(bx - ax, py - ay, -((by - ay) * (px - ax)));
+}
 
 struct RasterArgs
 {
@@ -38,11 +57,28 @@ struct RasterArgs
     const uint32_t* drawArgs;                                    // {numVisible, 1, 1}
     uint32_t* depth;                                             // R32F as bits
     uint32_t width, height;
+    BigTriangle* queue;                                          // scratch: [kQueueCapacity]
+    uint32_t* queueCount;                                        // scratch, zeroed before "main"
 };
 
-__device__ __forceinline__ float edgeFn(float ax, float ay, float bx, float by, float px, float py)
+// One triangle over the pixels [bx0, bx1] x [by0, by1], `threads` lanes striding over them from `first`; every covered
+// pixel goes to `sink(px, py, depthBits)`.  The arithmetic of orc_raster_depth, operation for operation.
+template <typename Sink>
+__device__ __forceinline__ void coverBox(float x0, float y0, float d0, float x1, float y1, float d1, float x2, float y2, float d2, float sgn,
+                                         uint32_t bx0, uint32_t by0, uint32_t bw, uint32_t bh, uint32_t first, uint32_t threads, Sink sink)
 {
-    return cm::fma_(bx - ax, py - ay, -((by - ay) * (px - ax)));
+    const uint64_t total = (uint64_t)bw * bh;
+    for (uint64_t i = first; i < total; i += threads) {
+        const uint32_t row = (uint32_t)(i / bw), col = (uint32_t)(i - (uint64_t)row * bw);
+        const uint32_t px = bx0 + col, py = by0 + row;
+        const float cx = (float)px + 0.5f, cy = (float)py + 0.5f;
+        const float e0 = sgn * edgeFn(x1, y1, x2, y2, cx, cy), e1 = sgn * edgeFn(x2, y2, x0, y0, cx, cy), e2 = sgn * edgeFn(x0, y0, x1, y1, cx, cy);
+        if (!(e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f)) continue;
+        const float den = (e0 + e1) + e2;
+        if (!(den > 0.0f)) continue;
+        const float d = cm::fma_(e2, d2, cm::fma_(e1, d1, e0 * d0)) / den;
+        if (d > 0.0f) sink(px, py, __float_as_uint(d));                                   // GREATER test; NaN never passes
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void rasterDepthKernel(RasterArgs a)
@@ -108,22 +144,87 @@ __global__ __launch_bounds__(kBlock) void rasterDepthKernel(RasterArgs a)
             const int by0 = (int)cm::max_(__builtin_floorf(fminy), 0.0f), by1 = (int)cm::min_(__builtin_ceilf(fmaxy), (float)(H - 1));
             if (bx1 < bx0 || by1 < by0) continue;
             const uint32_t bw = (uint32_t)(bx1 - bx0 + 1), bh = (uint32_t)(by1 - by0 + 1);
-            const uint64_t total = (uint64_t)bw * bh;
-            for (uint64_t i = lane; i < total; i += 64u) {
-                const uint32_t row = (uint32_t)(i / bw), col = (uint32_t)(i - (uint64_t)row * bw);
-                const uint32_t px = (uint32_t)bx0 + col, py = (uint32_t)by0 + row;
-                const float cx = (float)px + 0.5f, cy = (float)py + 0.5f;
-                const float e0 = sgn * edgeFn(x1, y1, x2, y2, cx, cy), e1 = sgn * edgeFn(x2, y2, x0, y0, cx, cy), e2 = sgn * edgeFn(x0, y0, x1, y1, cx, cy);
-                if (!(e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f)) continue;
-                const float den = (e0 + e1) + e2;
-                if (!(den > 0.0f)) continue;
-                const float d = cm::fma_(e2, d2, cm::fma_(e1, d1, e0 * d0)) / den;
-                if (d > 0.0f) atomicMax(&a.depth[(uint64_t)py * W + px], __float_as_uint(d));   // GREATER test; NaN never passes
+            if ((uint64_t)bw * bh > kSmallBox && a.queue) {                              // large on screen: the tile pass draws it
+                uint32_t slot = 0;
+                if (lane == 0) slot = atomicAdd(a.queueCount, 1u);
+                slot = __shfl(slot, 0);
+                if (slot < kQueueCapacity) {
+                    if (lane == 0) {
+                        BigTriangle q = { x0, y0, d0, x1, y1, d1, x2, y2, d2, sgn, (uint32_t)bx0 | ((uint32_t)bx1 << 16), (uint32_t)by0 | ((uint32_t)by1 << 16) };
+                        a.queue[slot] = q;
+                    }
+                    continue;
+                }
             }
+            uint32_t* depth = a.depth;
+            coverBox(x0, y0, d0, x1, y1, d1, x2, y2, d2, sgn, (uint32_t)bx0, (uint32_t)by0, bw, bh, lane, 64u,
+                     [depth, W](uint32_t px, uint32_t py, uint32_t bits) { atomicMax(&depth[(uint64_t)py * W + px], bits); });
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                           // the LDS slice is reused by the next meshlet
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+
+// The queued triangles, by screen tile.  Rounds of at most kTileList triangles: collect (all threads scan the queue,
+// LDS append), rasterise into the LDS tile, next round; then merge.  A tile is owned by one workgroup and this launch
+// follows "main" on the stream, so the merge needs no atomics.
+__global__ __launch_bounds__(kBlock) void rasterTilesKernel(RasterArgs a)
+{
+    __shared__ uint32_t s_depth[kTile * kTile];
+    __shared__ uint32_t s_list[kTileList];
+    __shared__ uint32_t s_count;
+    const uint32_t tid = threadIdx.x;
+    uint32_t n = *a.queueCount;
+    n = n < kQueueCapacity ? n : kQueueCapacity;
+    if (n == 0) return;
+    const uint32_t tilesX = (a.width + kTile - 1) / kTile, tilesY = (a.height + kTile - 1) / kTile;
+    for (uint32_t tile = blockIdx.x; tile < tilesX * tilesY; tile += gridDim.x) {
+        const uint32_t tx0 = (tile % tilesX) * kTile, ty0 = (tile / tilesX) * kTile;
+        const uint32_t tx1 = min(tx0 + kTile, a.width) - 1u, ty1 = min(ty0 + kTile, a.height) - 1u;
+        for (uint32_t i = tid; i < kTile * kTile; i += kBlock) s_depth[i] = 0u;
+        bool any = false;
+        for (uint32_t base = 0; base < n;) {
+            if (tid == 0) s_count = 0;
+            __syncthreads();
+            // collect: the scan stops early when the list is full; `base` advances to the first triangle not yet looked at
+            uint32_t next = base;
+            for (; next < n; next += kBlock) {
+                const uint32_t i = next + tid;
+                if (i < n) {
+                    const uint32_t bx = a.queue[i].boxX, by = a.queue[i].boxY;
+                    if ((bx & 0xFFFFu) <= tx1 && (bx >> 16) >= tx0 && (by & 0xFFFFu) <= ty1 && (by >> 16) >= ty0) {
+                        const uint32_t k = atomicAdd(&s_count, 1u);
+                        s_list[k] = i;                                                     // room for it: checked below before the next chunk
+                    }
+                }
+                __syncthreads();
+                const bool full = s_count + kBlock > kTileList;                            // the next chunk might not fit
+                __syncthreads();
+                if (full) { next += kBlock; break; }
+            }
+            base = next;
+            const uint32_t m = s_count;
+            any |= m != 0;
+            for (uint32_t k = 0; k < m; ++k) {
+                const BigTriangle q = a.queue[s_list[k]];
+                const uint32_t bx0 = max(q.boxX & 0xFFFFu, tx0), bx1 = min(q.boxX >> 16, tx1);
+                const uint32_t by0 = max(q.boxY & 0xFFFFu, ty0), by1 = min(q.boxY >> 16, ty1);
+                coverBox(q.x0, q.y0, q.d0, q.x1, q.y1, q.d1, q.x2, q.y2, q.d2, q.sgn, bx0, by0, bx1 - bx0 + 1u, by1 - by0 + 1u, tid, kBlock,
+                         [tx0, ty0](uint32_t px, uint32_t py, uint32_t bits) { atomicMax(&s_depth[(py - ty0) * kTile + (px - tx0)], bits); });
+            }
+            __syncthreads();
+        }
+        if (any) {
+            const uint32_t w = tx1 - tx0 + 1u, h = ty1 - ty0 + 1u;
+            for (uint32_t i = tid; i < w * h; i += kBlock) {
+                const uint32_t y = i / w, x = i - y * w;
+                const uint32_t v = s_depth[y * kTile + x];
+                if (v) { uint32_t* g = &a.depth[(uint64_t)(ty0 + y) * a.width + tx0 + x]; if (v > *g) *g = v; }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -164,10 +265,23 @@ int recordRasterDepth(trhip::DispatchCtx& ctx)
     a.drawArgs = (const uint32_t*)((const char*)ctx.argsBuffer->ptr + ctx.argsOffset);
     a.depth = (uint32_t*)depth->ptr;
     a.width = depth->width; a.height = depth->height;
+    TRHIP_REQUIRE(a.width <= 0xFFFFu && a.height <= 0xFFFFu, "%s: depth buffer %ux%u: at most 65535 pixels per side", ctx.shaderName, a.width, a.height);
+    // queue of the triangles that are large on screen: scratch of this command; its counter is zeroed by the recording's
+    // first clear launch
+    a.queue = (BigTriangle*)ctx.scratch((size_t)kQueueCapacity * sizeof(BigTriangle));
+    a.queueCount = (uint32_t*)ctx.scratch(16);
+    TRHIP_REQUIRE(a.queue && a.queueCount, "%s: scratch allocation failed", ctx.shaderName);
+    int rc = ctx.cl->recordClearWords(a.queueCount, 4, 0, true);
+    if (rc != TRHIP_OK) return rc;
     const uint32_t grid = ctx.computeUnits() * 4u;
     ctx.emit("main", [a, grid](hipStream_t s) {
         hipLaunchKernelGGL(rasterDepthKernel, dim3(grid), dim3(kBlock), 0, s, a);
         return trhip::launchStatus("rasterDepthKernel"); });
+    const uint32_t tiles = ((a.width + kTile - 1) / kTile) * ((a.height + kTile - 1) / kTile);
+    const uint32_t tileGrid = tiles < ctx.computeUnits() * 8u ? tiles : ctx.computeUnits() * 8u;
+    ctx.emit("tiles", [a, tileGrid](hipStream_t s) {
+        hipLaunchKernelGGL(rasterTilesKernel, dim3(tileGrid), dim3(kBlock), 0, s, a);
+        return trhip::launchStatus("rasterTilesKernel"); });
     return TRHIP_OK;
 }
 
