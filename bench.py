@@ -83,7 +83,8 @@ def cpu_baseline(spec: synth.SceneSpec, view, depth, sample_instances: int, thre
     same scene, same camera, same depth.  Checker code used as the reported CPU baseline only."""
     from oracle import pyoracle
     n = min(sample_instances, spec.num_instances)
-    n = (n // spec.chunk_meshes) * spec.chunk_meshes or min(spec.chunk_meshes, spec.num_instances)
+    if n < spec.num_instances:
+        n = (n // spec.chunk_meshes) * spec.chunk_meshes or min(spec.chunk_meshes, spec.num_instances)
     sub = synth.SceneSpec(**{**spec.__dict__, "num_meshes": n, "num_instances": n})
     full_md, _ = synth.gen_mesh_table(spec)
     md = full_md[:n].copy()
@@ -115,7 +116,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="C3")
-    ap.add_argument("--cpu-sample-instances", type=int, default=65536)
+    ap.add_argument("--cpu-sample-instances", type=int, default=1 << 30,
+                    help="instances of the scene the CPU baseline runs on (default: all of them; C3 = 3 frames of ~0.25 s on 64 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--flags", type=int, default=7, help="culling flags (7 = frustum+occlusion+cone, the headline config)")
@@ -308,7 +310,7 @@ def main():
     out = None
     if rank == 0:
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:           # reported at N=1 only (the host cores are shared by the ranks otherwise)
             try:
                 cpu = cpu_baseline(spec, view, depth, args.cpu_sample_instances, host_threads())
             except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU number
