@@ -29,6 +29,11 @@ void trhost_shutdown(void);
 int  trhost_load_scene(const void* instances, uint32_t num_instances, const void* mesh_data, uint32_t num_meshes,
                        const void* meshlets, uint64_t num_meshlets, const uint32_t* opaque_ids, uint32_t num_opaque,
                        const uint32_t* alpha_mask_ids, uint32_t num_alpha_mask);
+/* Same, with meshes, meshlets and the mesh-shader geometry read from a `<scene>_CachedData.bin` version 3, the
+ * reference's mesh-processing cache (SceneLoading.cpp:57-79 layout, :706-781 LoadCachedData); instances and id lists
+ * come from the caller (the glTF side).  Fails on another version, a truncated file or dangling ranges. */
+int  trhost_load_scene_cached(const char* cached_data_path, const void* instances, uint32_t num_instances, const uint32_t* opaque_ids, uint32_t num_opaque,
+                              const uint32_t* alpha_mask_ids, uint32_t num_alpha_mask);
 /* Large scenes: pass meshlets = NULL to trhost_load_scene (allocation only) and stream the meshlet
  * buffer in with this call. */
 int  trhost_upload_meshlets(uint64_t first_meshlet, const void* meshlets, uint64_t count);

@@ -248,3 +248,40 @@ def test_triangle_soup_with_hostile_vertices(dev, oracle, seed):
         for b in bufs:
             b.release()
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_scene_from_the_cached_data_file_through_the_native_reader(oracle, tmp_path):
+    """glTF -> `<scene>_CachedData.bin` v3 (cached_scene.write) -> the host library's own reader
+    (trhost_load_scene_cached: meshes, meshlets, vertices, meshlet index buffers from the file) -> two frames with
+    self-rendered depth: equal to the oracle on the in-memory scene.  A wrong version is refused."""
+    from test_gpu_parity import _compare_frame
+    from toyrenderer_amd import cached_scene, host
+    s = gltf_lite.load(write_city_gltf(tmp_path))
+    path = str(tmp_path / "city_CachedData.bin")
+    cached_scene.write(path, cached_scene.from_scene(s))
+    inst, sc = _world(oracle, s)
+    cam = s.cameras[0]
+    render = (960, 540)
+    view = gltf_lite.view_of(cam, render)
+    hzb = oracle.HzbTexture(*I.hzb_dims(*render))
+    depth = np.zeros((render[1], render[0]), np.float32)
+    r = host.Renderer(render=render, max_groups=4096)
+    try:
+        r.load_scene_cached(path, s.instances, s.opaqueIds, s.alphaMaskIds)
+        r.load_nodes(s.nodes, s.primToNode)
+        r.set_raster_depth(True)
+        r.set_culling(7)
+        geo = (I.world_to_clip(view.worldToView, view.viewToClip), s.vertices, s.meshletVertexIds, s.meshletTriangles)
+        for f in range(2):
+            r.set_node_transforms(s.nodes)
+            r.set_camera(view)
+            r.frame()
+            ref = oracle.frame(sc, view.as_dict(), hzb, depth, cullingFlags=7, record_capacity=4096, maxGroups=4096, raster=geo)
+            _compare_frame(r.results(), ref)
+            assert np.array_equal(r.download_depth().view(np.uint32), depth.view(np.uint32))
+        raw = bytearray(open(path, "rb").read()); raw[0] = 2
+        open(path, "wb").write(raw)
+        with pytest.raises(host.HostError, match="version 2"):
+            r.load_scene_cached(path, s.instances, s.opaqueIds, s.alphaMaskIds)
+    finally:
+        r.shutdown()

@@ -1,6 +1,11 @@
 // Scene.cpp -- see Scene.h.  Cites are to the reference's source/Scene.cpp.
 #include "Scene.h"
 
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
 #include "HostProfile.h"
 
 #include <cstring>
@@ -72,6 +77,50 @@ void Scene::LoadFromArrays(const void* instances, uint32_t numInstances, const v
     upload(m_OpaqueInstanceIDsBuffer, opaqueIds, (uint64_t)numOpaque * 4);
     m_AlphaMaskInstanceIDsBuffer = make("AlphaMaskInstanceIDsBuffer", (uint64_t)numAlphaMask * 4, 4, false);
     upload(m_AlphaMaskInstanceIDsBuffer, alphaMaskIds, (uint64_t)numAlphaMask * 4);
+}
+
+void Scene::LoadCachedData(const char* path, const void* instances, uint32_t numInstances, const uint32_t* opaqueIds, uint32_t numOpaque,
+                           const uint32_t* alphaMaskIds, uint32_t numAlphaMask)
+{
+    // SceneLoading.cpp:57-79
+    struct Header { uint32_t m_Version, m_MeshOptVersion, m_NumVertices, m_NumIndices, m_NumMeshes, m_NumMeshletVertexIdxOffsets, m_NumMeshletIndices, m_NumMeshletDatas; };
+    static_assert(sizeof(Header) == 32, "CachedData::Header");
+    constexpr uint32_t kCurrentVersion = 3;
+    constexpr size_t kRawVertexFormatBytes = 20, kMeshSpecificDataBytes = 32;
+    struct File { FILE* f; ~File() { if (f) fclose(f); } } file{ fopen(path, "rb") };
+    if (!file.f) throw std::runtime_error(std::string("cached data: cannot open ") + path);
+    Header h{};
+    if (fread(&h, sizeof h, 1, file.f) != 1) throw std::runtime_error("cached data: no header");
+    if (h.m_Version != kCurrentVersion) throw std::runtime_error("cached data: version " + std::to_string(h.m_Version) + ", this reader handles 3");
+    auto take = [&](std::vector<uint8_t>& dst, size_t elemBytes, uint64_t count, const char* what) {     // :728-748, same order
+        dst.resize((size_t)(elemBytes * count));
+        if (count && fread(dst.data(), elemBytes, (size_t)count, file.f) != count) throw std::runtime_error(std::string("cached data: truncated in ") + what);
+    };
+    std::vector<uint8_t> vertices, indices, meshData, vertexIds, triangles, meshlets, meshSpecific;
+    take(vertices, kRawVertexFormatBytes, h.m_NumVertices, "vertices");
+    take(indices, sizeof(uint32_t), h.m_NumIndices, "indices");
+    take(meshData, sizeof(interop::MeshData), h.m_NumMeshes, "mesh data");
+    take(vertexIds, sizeof(uint32_t), h.m_NumMeshletVertexIdxOffsets, "meshlet vertex ids");
+    take(triangles, sizeof(uint32_t), h.m_NumMeshletIndices, "meshlet triangles");
+    take(meshlets, sizeof(interop::MeshletData), h.m_NumMeshletDatas, "meshlets");
+    take(meshSpecific, kMeshSpecificDataBytes, h.m_NumMeshes, "mesh specific data");
+    // the ranges the cull and the mesh shader follow blindly
+    const interop::MeshData* md = (const interop::MeshData*)meshData.data();
+    for (uint32_t i = 0; i < h.m_NumMeshes; ++i) {
+        if (md[i].m_NumLODs < 1 || md[i].m_NumLODs > interop::kMaxNumMeshLODs) throw std::runtime_error("cached data: mesh " + std::to_string(i) + " has a bad LOD count");
+        for (uint32_t l = 0; l < md[i].m_NumLODs; ++l)
+            if ((uint64_t)md[i].m_MeshLODDatas[l].m_MeshletDataBufferIdx + md[i].m_MeshLODDatas[l].m_NumMeshlets > h.m_NumMeshletDatas)
+                throw std::runtime_error("cached data: mesh " + std::to_string(i) + " points past the meshlet buffer");
+    }
+    const interop::MeshletData* ml = (const interop::MeshletData*)meshlets.data();
+    for (uint32_t i = 0; i < h.m_NumMeshletDatas; ++i) {
+        const uint32_t nv = ml[i].m_VertexAndTriangleCount & 0xFFu, nt = (ml[i].m_VertexAndTriangleCount >> 8) & 0xFFu;
+        if ((uint64_t)ml[i].m_MeshletVertexIDsBufferIdx + nv > h.m_NumMeshletVertexIdxOffsets || (uint64_t)ml[i].m_MeshletIndexIDsBufferIdx + nt > h.m_NumMeshletIndices)
+            throw std::runtime_error("cached data: meshlet " + std::to_string(i) + " points past its index buffers");
+    }
+    LoadFromArrays(instances, numInstances, meshData.data(), h.m_NumMeshes, meshlets.data(), h.m_NumMeshletDatas, opaqueIds, numOpaque, alphaMaskIds, numAlphaMask);
+    LoadGeometry(vertices.data(), h.m_NumVertices, (const uint32_t*)vertexIds.data(), h.m_NumMeshletVertexIdxOffsets,
+                 (const uint32_t*)triangles.data(), h.m_NumMeshletIndices);
 }
 
 void Scene::LoadGeometry(const void* vertices, uint64_t numVertices, const uint32_t* meshletVertexIds, uint64_t numVertexIds,

@@ -81,6 +81,10 @@ public:
     // Instead of the stand-in: every pass rasterises the depth of its visible meshlets ("basepass_MS_Main_depth", the
     // compute replacement of MS_Main + depth test) into the depth buffer, cleared at the start of the base pass.
     bool m_bRasterDepth = false;
+    // `<scene>_CachedData.bin` version 3 (SceneLoading.cpp:57-79 layout, :706-781 LoadCachedData): meshes, meshlets and
+    // the mesh-shader geometry come from the file, instances and id lists from the caller (the glTF side of the reference).
+    void LoadCachedData(const char* path, const void* instances, uint32_t numInstances, const uint32_t* opaqueIds, uint32_t numOpaque,
+                        const uint32_t* alphaMaskIds, uint32_t numAlphaMask);
     void LoadGeometry(const void* vertices, uint64_t numVertices, const uint32_t* meshletVertexIds, uint64_t numVertexIds,
                       const uint32_t* meshletTriangles, uint64_t numTriangles);
 

@@ -79,6 +79,16 @@ int trhost_upload_meshlets(uint64_t first_meshlet, const void* meshlets, uint64_
     });
 }
 
+int trhost_load_scene_cached(const char* cached_data_path, const void* instances, uint32_t num_instances, const uint32_t* opaque_ids, uint32_t num_opaque,
+                             const uint32_t* alpha_mask_ids, uint32_t num_alpha_mask)
+{
+    return guarded([&] {
+        check(cached_data_path && instances);
+        g_Scene->LoadCachedData(cached_data_path, instances, num_instances, opaque_ids, num_opaque, alpha_mask_ids, num_alpha_mask);
+        g_Graphic.PostSceneLoad();
+    });
+}
+
 int trhost_load_geometry(const void* vertices, uint64_t num_vertices, const uint32_t* meshlet_vertex_ids, uint64_t num_vertex_ids,
                          const uint32_t* meshlet_triangles, uint64_t num_triangles)
 {

@@ -22,6 +22,7 @@ HOST_SYMBOLS = [
     "trhost_heap_sim", "trhost_set_shard_late_exchange", "trhost_set_gpu_timers",
     "trhost_rccl_allgather", "trhost_exchange_create", "trhost_exchange_run", "trhost_exchange_wait", "trhost_exchange_outputs",
     "trhost_exchange_destroy", "trhost_load_geometry", "trhost_set_raster_depth", "trhost_download_depth",
+    "trhost_load_scene_cached",
 ]
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)   # trhost_allgather_fn
@@ -69,6 +70,7 @@ def load() -> C.CDLL:
     L.trhost_set_limits.argtypes = [u32, u64]
     L.trhost_upload_depth.argtypes = [vp, u32, u32]
     L.trhost_load_geometry.argtypes = [vp, u64, vp, u64, vp, u64]
+    L.trhost_load_scene_cached.argtypes = [C.c_char_p, vp, u32, vp, u32, vp, u32]
     L.trhost_set_raster_depth.argtypes = [C.c_int]
     L.trhost_download_depth.argtypes = [vp, u64]
     L.trhost_upload_hzb_mip.argtypes = [u32, vp, u64]
@@ -137,6 +139,15 @@ class Renderer:
         _check(load().trhost_load_scene(a[0].ctypes.data, len(a[0]), a[1].ctypes.data, len(a[1]),
                                         ml.ctypes.data if ml is not None else None, len(ml) if ml is not None else int(num_meshlets),
                                         op.ctypes.data if op.size else None, op.size, am.ctypes.data if am.size else None, am.size))
+        self.num_opaque, self.num_alpha = op.size, am.size
+
+    def load_scene_cached(self, cached_data_path: str, instances, opaqueIds, alphaMaskIds):
+        """Meshes, meshlets and geometry from a `<scene>_CachedData.bin` v3 (read natively), instances / id lists from the caller."""
+        a = np.ascontiguousarray(instances)
+        op = np.ascontiguousarray(opaqueIds, np.uint32)
+        am = np.ascontiguousarray(alphaMaskIds, np.uint32)
+        _check(load().trhost_load_scene_cached(os.fsencode(cached_data_path), a.ctypes.data, len(a), op.ctypes.data if op.size else None, op.size,
+                                               am.ctypes.data if am.size else None, am.size))
         self.num_opaque, self.num_alpha = op.size, am.size
 
     def upload_meshlets(self, first: int, meshlets):
