@@ -14,7 +14,8 @@
 // slice, then the wave walks the triangles one after the other, 64 pixels of the bounding box per pass; a triangle whose
 // box exceeds kSmallBox pixels is not drawn there but appended to a queue (screen positions, depths, box).  "tiles": one
 // workgroup per 64x64-pixel screen tile collects the queued triangles that touch it and rasterises them into an LDS copy
-// of the tile, 4096 pixels at a time, then merges the tile into the depth buffer.  Without the second launch a dozen
+// of the tile, 4096 pixels at a time, then merges the tile into the depth buffer; it looks for them in the list of its
+// 256x256-pixel coarse bin, which "main" fills while it queues.  Without the second launch a dozen
 // waves walked the 10^4-pixel boxes of a near wall while the chip idled (3.2 ms per pass at 3840x2160,
 // tools/raster_time.py).  Every pixel value is computed by the same operations whichever launch produces it.
 #include "cull_math.hip.h"
@@ -31,6 +32,8 @@ constexpr uint32_t kSmallBox = 1024;            // pixels: larger bounding boxes
 constexpr uint32_t kTile = 64;                  // pixels per side
 constexpr uint32_t kQueueCapacity = 1u << 20;   // 48 MB; beyond it triangles are drawn in place (slow, still exact)
 constexpr uint32_t kTileList = 1024;            // queued triangles a tile handles per round
+constexpr uint32_t kBinShift = 8;               // coarse bins of 256x256 pixels (4x4 tiles): a tile scans its bin's list, not the whole queue
+constexpr uint32_t kBinCapacity = 1u << 16;     // queue indices per bin; a fuller bin makes its tiles scan the whole queue
 
 struct BigTriangle                              // 48 bytes
 {
@@ -59,6 +62,9 @@ struct RasterArgs
     uint32_t width, height;
     BigTriangle* queue;                                          // scratch: [kQueueCapacity]
     uint32_t* queueCount;                                        // scratch, zeroed before "main"
+    uint32_t* binCount;                                          // scratch, zeroed: [binsX * binsY] entries appended (may exceed the capacity)
+    uint32_t* binList;                                           // scratch: [binsX * binsY][kBinCapacity] queue indices
+    uint32_t binsX, binsY;
 };
 
 // One triangle over the pixels [bx0, bx1] x [by0, by1], `threads` lanes striding over them from `first`; every covered
@@ -153,6 +159,14 @@ __global__ __launch_bounds__(kBlock) void rasterDepthKernel(RasterArgs a)
                         BigTriangle q = { x0, y0, d0, x1, y1, d1, x2, y2, d2, sgn, (uint32_t)bx0 | ((uint32_t)bx1 << 16), (uint32_t)by0 | ((uint32_t)by1 << 16) };
                         a.queue[slot] = q;
                     }
+                    // its index goes to every coarse bin the box touches (lanes share the bins)
+                    const uint32_t cx0 = (uint32_t)bx0 >> kBinShift, cx1 = (uint32_t)bx1 >> kBinShift, cy0 = (uint32_t)by0 >> kBinShift, cy1 = (uint32_t)by1 >> kBinShift;
+                    const uint32_t cw = cx1 - cx0 + 1u, nb = cw * (cy1 - cy0 + 1u);
+                    for (uint32_t j = lane; j < nb; j += 64u) {
+                        const uint32_t bin = (cy0 + j / cw) * a.binsX + cx0 + j % cw;
+                        const uint32_t k = atomicAdd(&a.binCount[bin], 1u);
+                        if (k < kBinCapacity) a.binList[(uint64_t)bin * kBinCapacity + k] = slot;
+                    }
                     continue;
                 }
             }
@@ -185,14 +199,21 @@ __global__ __launch_bounds__(kBlock) void rasterTilesKernel(RasterArgs a)
         const uint32_t tx1 = min(tx0 + kTile, a.width) - 1u, ty1 = min(ty0 + kTile, a.height) - 1u;
         for (uint32_t i = tid; i < kTile * kTile; i += kBlock) s_depth[i] = 0u;
         bool any = false;
-        for (uint32_t base = 0; base < n;) {
+        // candidates: the list of the tile's coarse bin, or the whole queue when that list overflowed
+        const uint32_t bin = (ty0 >> kBinShift) * a.binsX + (tx0 >> kBinShift);
+        const uint32_t binned = a.binCount[bin];
+        const bool wholeQueue = binned > kBinCapacity;
+        const uint32_t* candidates = a.binList + (uint64_t)bin * kBinCapacity;
+        const uint32_t nCand = wholeQueue ? n : binned;
+        for (uint32_t base = 0; base < nCand;) {
             if (tid == 0) s_count = 0;
             __syncthreads();
             // collect: the scan stops early when the list is full; `base` advances to the first triangle not yet looked at
             uint32_t next = base;
-            for (; next < n; next += kBlock) {
-                const uint32_t i = next + tid;
-                if (i < n) {
+            for (; next < nCand; next += kBlock) {
+                const uint32_t c = next + tid;
+                if (c < nCand) {
+                    const uint32_t i = wholeQueue ? c : candidates[c];
                     const uint32_t bx = a.queue[i].boxX, by = a.queue[i].boxY;
                     if ((bx & 0xFFFFu) <= tx1 && (bx >> 16) >= tx0 && (by & 0xFFFFu) <= ty1 && (by >> 16) >= ty0) {
                         const uint32_t k = atomicAdd(&s_count, 1u);
@@ -271,7 +292,14 @@ int recordRasterDepth(trhip::DispatchCtx& ctx)
     a.queue = (BigTriangle*)ctx.scratch((size_t)kQueueCapacity * sizeof(BigTriangle));
     a.queueCount = (uint32_t*)ctx.scratch(16);
     TRHIP_REQUIRE(a.queue && a.queueCount, "%s: scratch allocation failed", ctx.shaderName);
+    a.binsX = (a.width + (1u << kBinShift) - 1u) >> kBinShift;
+    a.binsY = (a.height + (1u << kBinShift) - 1u) >> kBinShift;
+    const uint32_t bins = a.binsX * a.binsY;
+    a.binCount = (uint32_t*)ctx.scratch((size_t)bins * 4);
+    a.binList = (uint32_t*)ctx.scratch((size_t)bins * kBinCapacity * 4);
+    TRHIP_REQUIRE(a.binCount && a.binList, "%s: scratch allocation failed", ctx.shaderName);
     int rc = ctx.cl->recordClearWords(a.queueCount, 4, 0, true);
+    if (rc == TRHIP_OK) rc = ctx.cl->recordClearWords(a.binCount, bins, 0, true);
     if (rc != TRHIP_OK) return rc;
     const uint32_t grid = ctx.computeUnits() * 4u;
     ctx.emit("main", [a, grid](hipStream_t s) {

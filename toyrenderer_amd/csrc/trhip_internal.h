@@ -178,7 +178,7 @@ struct trhip_cmdlist_t
 
     // Consecutive buffer clears are issued as ONE kernel launch (a frame has ~11 clears of a few bytes
     // each; a launch costs ~5 us on both sides of the queue).
-    struct ClearBatch { static constexpr uint32_t kMax = 16; void* ptr[kMax]; uint64_t words[kMax]; uint32_t value[kMax]; uint32_t count = 0; };
+    struct ClearBatch { static constexpr uint32_t kMax = 32; void* ptr[kMax]; uint64_t words[kMax]; uint32_t value[kMax]; uint32_t count = 0; };
     std::shared_ptr<ClearBatch> openClearBatch;    // batch of the LAST op in `ops`, if that op is a clear
     size_t openClearOp = SIZE_MAX;
     // A clear of memory that no earlier command of this recording uses joins the FIRST clear launch of the recording
