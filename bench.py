@@ -143,7 +143,7 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
-    force_gather = bool(os.environ.get("TR_FORCE_GATHER")) or args.emulate_ranks > 1     # exercise the RCCL path with a 1-rank group (tests)
+    force_gather = (bool(os.environ.get("TR_FORCE_GATHER")) or args.emulate_ranks > 1) and not os.environ.get("TR_NO_GATHER")     # exercise the RCCL path with a 1-rank group (tests)
     shard_world, shard_rank = (args.emulate_ranks, 0) if args.emulate_ranks > 1 else (world, rank)
     if world > 1 or force_gather:
         import torch.distributed as dist

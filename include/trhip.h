@@ -198,6 +198,10 @@ int  trhip_profile_entry(trhip_device dev, uint32_t index, const char** name, ui
  * streams next to the renderer's).  Plain wrappers: hipStreamCreateWithFlags(NonBlocking), hipEventCreateWithFlags
  * (DisableTiming), hipEventRecord, hipStreamWaitEvent, hipStreamSynchronize. */
 int  trhip_stream_create(int device_index, void** out_hip_stream);
+/* priority_class < 0: the device's highest stream priority, 0: default, > 0: lowest (hipStreamCreateWithPriority).
+ * Streams of different priority classes never share a hardware queue; streams of one class may (HIP multiplexes them
+ * round robin onto GPU_MAX_HW_QUEUES queues) and then run one after the other. */
+int  trhip_stream_create_priority(int device_index, int priority_class, void** out_hip_stream);
 void trhip_stream_destroy(void* hip_stream);
 int  trhip_stream_synchronize(void* hip_stream);
 int  trhip_event_create(int device_index, void** out_hip_event);

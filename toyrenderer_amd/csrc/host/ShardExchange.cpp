@@ -191,9 +191,11 @@ void ShardExchangeCreate(const trhost_exchange_desc& d)
     x.slotWords = kHeaderWords + 4u * d.slot_groups;
     x.compute = g_Graphic.m_NVRHIDevice->native();
     x.deviceIndex = g_Graphic.m_DeviceIndex;
-    require(trhip_stream_create(x.deviceIndex, &x.auxStream), "exchange: aux stream");
+    // the late-count exchange is tiny and the frame waits for it: highest priority; the slot exchange is background work
+    // behind the next frame: lowest.  Different classes than the renderer's stream = hardware queues of their own.
+    require(trhip_stream_create_priority(x.deviceIndex, -1, &x.auxStream), "exchange: aux stream");
     if (d.overlap) {
-        require(trhip_stream_create(x.deviceIndex, &x.commStream), "exchange: stream");
+        require(trhip_stream_create_priority(x.deviceIndex, +1, &x.commStream), "exchange: stream");
         require(trhip_device_create_on_stream(x.deviceIndex, x.commStream, &x.commDev), "exchange: device on the exchange stream");
     } else {
         require(trhip_device_create_on_stream(x.deviceIndex, trhip_device_stream(x.compute), &x.commDev), "exchange: device on the compute stream");

@@ -281,7 +281,13 @@ static int deviceCreate(int index, void* stream, bool external, trhip_device* ou
         dev->ownsStream = true;
     }
     if (!getenv("TRHIP_NO_SIDE_STREAM")) {             // see trhip_device_t::sideStream
-        TRHIP_HIP(hipStreamCreateWithFlags(&dev->sideStream, hipStreamNonBlocking));
+        // High priority: HIP multiplexes the streams of one priority class onto a few hardware queues (4 by default)
+        // round robin; in a process with many streams (torch, RCCL) the side stream otherwise lands on the SAME
+        // hardware queue as the main stream sooner or later and its kernels serialise with it (seen at 2-8 ranks:
+        // +0.06..0.16 ms per frame).  A different priority class is a different queue.
+        int lowest = 0, highest = 0;
+        TRHIP_HIP(hipDeviceGetStreamPriorityRange(&lowest, &highest));
+        TRHIP_HIP(hipStreamCreateWithPriority(&dev->sideStream, hipStreamNonBlocking, highest));
         TRHIP_HIP(hipEventCreateWithFlags(&dev->evFork, hipEventDisableTiming));
         for (hipEvent_t& e : dev->runDone) TRHIP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
@@ -856,15 +862,19 @@ int trhip_queue_execute(trhip_device dev, const trhip_cmdlist* lists, uint32_t n
 }
 
 // ---- streams / events for callers that order work across streams themselves ------------------------------
-int trhip_stream_create(int device_index, void** out)
+int trhip_stream_create_priority(int device_index, int priority_class, void** out)
 {
     if (!out) return fail(TRHIP_ERR_INVALID, "stream_create: out is null");
     TRHIP_HIP(hipSetDevice(device_index));
+    int lowest = 0, highest = 0;
+    TRHIP_HIP(hipDeviceGetStreamPriorityRange(&lowest, &highest));      // numerically: highest <= 0 <= lowest
     hipStream_t s = nullptr;
-    TRHIP_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    TRHIP_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority_class < 0 ? highest : priority_class > 0 ? lowest : 0));
     *out = (void*)s;
     return TRHIP_OK;
 }
+
+int trhip_stream_create(int device_index, void** out) { return trhip_stream_create_priority(device_index, 0, out); }
 
 void trhip_stream_destroy(void* s)
 {

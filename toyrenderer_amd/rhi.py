@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "trhip_timer_create", "trhip_timer_release", "trhip_timer_get_ms",
     "trhip_profile_enable", "trhip_profile_reset", "trhip_profile_count", "trhip_profile_entry",
     "trhip_launch_shard_late_info",
-    "trhip_stream_create", "trhip_stream_destroy", "trhip_stream_synchronize", "trhip_event_create", "trhip_event_destroy",
+    "trhip_stream_create", "trhip_stream_create_priority", "trhip_stream_destroy", "trhip_stream_synchronize", "trhip_event_create", "trhip_event_destroy",
     "trhip_event_record", "trhip_stream_wait_event",
 ]
 
@@ -128,6 +128,7 @@ def load() -> C.CDLL:
     L.trhip_cmd_host_callback.argtypes = [vp, HOST_FN, vp]
     L.trhip_launch_shard_late_info.argtypes = [vp, vp, u32, u32, vp]
     L.trhip_stream_create.argtypes = [i32, C.POINTER(vp)]
+    L.trhip_stream_create_priority.argtypes = [i32, i32, C.POINTER(vp)]
     L.trhip_stream_destroy.argtypes = [vp]
     L.trhip_stream_destroy.restype = None
     L.trhip_stream_synchronize.argtypes = [vp]
