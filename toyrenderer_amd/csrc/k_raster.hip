@@ -189,6 +189,7 @@ __global__ __launch_bounds__(kBlock) void rasterTilesKernel(RasterArgs a)
     __shared__ uint32_t s_depth[kTile * kTile];
     __shared__ uint32_t s_list[kTileList];
     __shared__ uint32_t s_count;
+    __shared__ uint32_t s_waveMin[kWaves];
     const uint32_t tid = threadIdx.x;
     uint32_t n = *a.queueCount;
     n = n < kQueueCapacity ? n : kQueueCapacity;
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(kBlock) void rasterTilesKernel(RasterArgs a)
         const uint32_t tx1 = min(tx0 + kTile, a.width) - 1u, ty1 = min(ty0 + kTile, a.height) - 1u;
         for (uint32_t i = tid; i < kTile * kTile; i += kBlock) s_depth[i] = 0u;
         bool any = false;
+        float tileFar = 0.0f;                                                            // farthest depth in the tile (0 = something still uncovered)
         // candidates: the list of the tile's coarse bin, or the whole queue when that list overflowed
         const uint32_t bin = (ty0 >> kBinShift) * a.binsX + (tx0 >> kBinShift);
         const uint32_t binned = a.binCount[bin];
@@ -229,7 +231,22 @@ __global__ __launch_bounds__(kBlock) void rasterTilesKernel(RasterArgs a)
             const uint32_t m = s_count;
             any |= m != 0;
             for (uint32_t k = 0; k < m; ++k) {
+                // Every 32 triangles: the farthest depth the tile holds so far.  A triangle none of whose samples can be
+                // nearer than that cannot change a maximum and is skipped (its samples are at most max(d0,d1,d2) times
+                // (1 + 6 * 2^-24): three roundings in the fma chain, two in the sum of the weights, one in the division).
+                if ((k & 31u) == 0u && (k != 0u || any)) {
+                    uint32_t mn = 0xFFFFFFFFu;
+                    const uint32_t w = tx1 - tx0 + 1u, h = ty1 - ty0 + 1u;
+                    for (uint32_t i = tid; i < w * h; i += kBlock) { const uint32_t y = i / w, x = i - y * w; mn = min(mn, s_depth[y * kTile + x]); }
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, d));
+                    __syncthreads();                                                     // the previous value has been read by everyone
+                    if ((tid & 63u) == 0u) s_waveMin[tid >> 6] = mn;
+                    __syncthreads();
+                    tileFar = __uint_as_float(min(min(s_waveMin[0], s_waveMin[1]), min(s_waveMin[2], s_waveMin[3])));   // depths are > 0: bit order = value order
+                }
                 const BigTriangle q = a.queue[s_list[k]];
+                if (cm::max_(cm::max_(q.d0, q.d1), q.d2) * 0x1.00001p+0f < tileFar) continue;     // NaN or inf: never skipped
                 const uint32_t bx0 = max(q.boxX & 0xFFFFu, tx0), bx1 = min(q.boxX >> 16, tx1);
                 const uint32_t by0 = max(q.boxY & 0xFFFFu, ty0), by1 = min(q.boxY >> 16, ty1);
                 coverBox(q.x0, q.y0, q.d0, q.x1, q.y1, q.d1, q.x2, q.y2, q.d2, q.sgn, bx0, by0, bx1 - bx0 + 1u, by1 - by0 + 1u, tid, kBlock,
