@@ -11,8 +11,9 @@
 // result is a maximum, so it does not depend on the order the triangles are drawn in: bit-exact against the oracle.
 //
 // Two launches.  "main": one wave per visible meshlet -- lanes transform the (<= 64) vertices into the wave's LDS
-// slice, then the wave walks the triangles one after the other, 64 pixels of the bounding box per pass; a triangle whose
-// box exceeds kSmallBox pixels is not drawn there but appended to a queue (screen positions, depths, box).  "tiles": one
+// slice, then set up the triangles (lane t: triangle t); a triangle whose box exceeds kSmallBox pixels is appended to a
+// queue (screen positions, depths, box; one counter update per wave), the others are drawn by the wave one after the
+// other, 64 pixels of the bounding box per pass.  "tiles": one
 // workgroup per 64x64-pixel screen tile collects the queued triangles that touch it and rasterises them into an LDS copy
 // of the tile, 4096 pixels at a time, then merges the tile into the depth buffer; it looks for them in the list of its
 // 256x256-pixel coarse bin, which "main" fills while it queues.  Without the second launch a dozen
@@ -90,6 +91,7 @@ __device__ __forceinline__ void coverBox(float x0, float y0, float d0, float x1,
 __global__ __launch_bounds__(kBlock) void rasterDepthKernel(RasterArgs a)
 {
     __shared__ float s_x[kWaves][64], s_y[kWaves][64], s_d[kWaves][64];
+    __shared__ BigTriangle s_tri[kWaves][64];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     float* sx = s_x[wave]; float* sy = s_y[wave]; float* sd = s_d[wave];
     uint32_t V = a.drawArgs[0];
@@ -132,47 +134,78 @@ __global__ __launch_bounds__(kBlock) void rasterDepthKernel(RasterArgs a)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- triangles (:178-187), one after the other; 64 pixels of the bounding box per pass -------------------
-        for (uint32_t t = 0; t < nt; ++t) {
-            const uint32_t packed = a.triangles[ml.m_MeshletIndexIDsBufferIdx + t];
-            const uint32_t ia = packed & 0xFFu, ib = (packed >> 8) & 0xFFu, ic = (packed >> 16) & 0xFFu;
-            if (ia >= nv || ib >= nv || ic >= nv) continue;
-            if (!((okMask >> ia) & (okMask >> ib) & (okMask >> ic) & 1ull)) continue;
-            const float x0 = sx[ia], y0 = sy[ia], x1 = sx[ib], y1 = sy[ib], x2 = sx[ic], y2 = sy[ic];
-            const float d0 = sd[ia], d1 = sd[ib], d2 = sd[ic];
-            const float area = edgeFn(x0, y0, x1, y1, x2, y2);
-            if (!(area != 0.0f)) continue;                                               // degenerate or NaN
-            const float sgn = area < 0.0f ? -1.0f : 1.0f;
-            const float fminx = cm::min_(cm::min_(x0, x1), x2), fmaxx = cm::max_(cm::max_(x0, x1), x2);
-            const float fminy = cm::min_(cm::min_(y0, y1), y2), fmaxy = cm::max_(cm::max_(y0, y1), y2);
-            if (!(fmaxx >= 0.0f && fmaxy >= 0.0f && fminx <= (float)W && fminy <= (float)H)) continue;   // off screen or NaN
-            const int bx0 = (int)cm::max_(__builtin_floorf(fminx), 0.0f), bx1 = (int)cm::min_(__builtin_ceilf(fmaxx), (float)(W - 1));
-            const int by0 = (int)cm::max_(__builtin_floorf(fminy), 0.0f), by1 = (int)cm::min_(__builtin_ceilf(fmaxy), (float)(H - 1));
-            if (bx1 < bx0 || by1 < by0) continue;
-            const uint32_t bw = (uint32_t)(bx1 - bx0 + 1), bh = (uint32_t)(by1 - by0 + 1);
-            if ((uint64_t)bw * bh > kSmallBox && a.queue) {                              // large on screen: the tile pass draws it
-                uint32_t slot = 0;
-                if (lane == 0) slot = atomicAdd(a.queueCount, 1u);
-                slot = __shfl(slot, 0);
-                if (slot < kQueueCapacity) {
-                    if (lane == 0) {
-                        BigTriangle q = { x0, y0, d0, x1, y1, d1, x2, y2, d2, sgn, (uint32_t)bx0 | ((uint32_t)bx1 << 16), (uint32_t)by0 | ((uint32_t)by1 << 16) };
-                        a.queue[slot] = q;
+        // ---- triangles (:178-187).  Set-up in parallel: lane t prepares triangle t (64 at a time); the large ones are
+        //      queued with ONE counter update per wave, the others are then drawn one after the other, 64 pixels of the
+        //      bounding box per pass -----------------------------------------------------------------------------------
+        BigTriangle* st = s_tri[wave];
+        for (uint32_t tb = 0; tb < nt; tb += 64u) {
+            const uint32_t t = tb + lane;
+            bool live = false;
+            BigTriangle q = {};
+            uint32_t bw = 0, bh = 0;
+            if (t < nt) {
+                const uint32_t packed = a.triangles[ml.m_MeshletIndexIDsBufferIdx + t];
+                const uint32_t ia = packed & 0xFFu, ib = (packed >> 8) & 0xFFu, ic = (packed >> 16) & 0xFFu;
+                if (ia < nv && ib < nv && ic < nv && ((okMask >> ia) & (okMask >> ib) & (okMask >> ic) & 1ull)) {
+                    q.x0 = sx[ia]; q.y0 = sy[ia]; q.x1 = sx[ib]; q.y1 = sy[ib]; q.x2 = sx[ic]; q.y2 = sy[ic];
+                    q.d0 = sd[ia]; q.d1 = sd[ib]; q.d2 = sd[ic];
+                    const float area = edgeFn(q.x0, q.y0, q.x1, q.y1, q.x2, q.y2);
+                    const float fminx = cm::min_(cm::min_(q.x0, q.x1), q.x2), fmaxx = cm::max_(cm::max_(q.x0, q.x1), q.x2);
+                    const float fminy = cm::min_(cm::min_(q.y0, q.y1), q.y2), fmaxy = cm::max_(cm::max_(q.y0, q.y1), q.y2);
+                    if (area != 0.0f                                                          // not degenerate, not NaN
+                        && fmaxx >= 0.0f && fmaxy >= 0.0f && fminx <= (float)W && fminy <= (float)H) {   // on screen, not NaN
+                        q.sgn = area < 0.0f ? -1.0f : 1.0f;
+                        const int bx0 = (int)cm::max_(__builtin_floorf(fminx), 0.0f), bx1 = (int)cm::min_(__builtin_ceilf(fmaxx), (float)(W - 1));
+                        const int by0 = (int)cm::max_(__builtin_floorf(fminy), 0.0f), by1 = (int)cm::min_(__builtin_ceilf(fmaxy), (float)(H - 1));
+                        if (bx1 >= bx0 && by1 >= by0) {
+                            live = true;
+                            bw = (uint32_t)(bx1 - bx0 + 1); bh = (uint32_t)(by1 - by0 + 1);
+                            q.boxX = (uint32_t)bx0 | ((uint32_t)bx1 << 16); q.boxY = (uint32_t)by0 | ((uint32_t)by1 << 16);
+                        }
                     }
-                    // its index goes to every coarse bin the box touches (lanes share the bins)
-                    const uint32_t cx0 = (uint32_t)bx0 >> kBinShift, cx1 = (uint32_t)bx1 >> kBinShift, cy0 = (uint32_t)by0 >> kBinShift, cy1 = (uint32_t)by1 >> kBinShift;
-                    const uint32_t cw = cx1 - cx0 + 1u, nb = cw * (cy1 - cy0 + 1u);
-                    for (uint32_t j = lane; j < nb; j += 64u) {
-                        const uint32_t bin = (cy0 + j / cw) * a.binsX + cx0 + j % cw;
-                        const uint32_t k = atomicAdd(&a.binCount[bin], 1u);
-                        if (k < kBinCapacity) a.binList[(uint64_t)bin * kBinCapacity + k] = slot;
-                    }
-                    continue;
                 }
             }
-            uint32_t* depth = a.depth;
-            coverBox(x0, y0, d0, x1, y1, d1, x2, y2, d2, sgn, (uint32_t)bx0, (uint32_t)by0, bw, bh, lane, 64u,
-                     [depth, W](uint32_t px, uint32_t py, uint32_t bits) { atomicMax(&depth[(uint64_t)py * W + px], bits); });
+            // large on screen: the tile pass draws them
+            bool big = live && (uint64_t)bw * bh > kSmallBox && a.queue != nullptr;
+            const unsigned long long bigMask = __ballot(big);
+            if (bigMask) {
+                uint32_t first = 0;
+                if (lane == 0) first = atomicAdd(a.queueCount, (uint32_t)__popcll(bigMask));
+                first = __shfl(first, 0);
+                const uint32_t slot = first + (uint32_t)__popcll(bigMask & ((1ull << lane) - 1ull));
+                if (big && slot < kQueueCapacity) {
+                    a.queue[slot] = q;
+                    // its index goes to every coarse bin the box touches
+                    const uint32_t cx0 = (q.boxX & 0xFFFFu) >> kBinShift, cx1 = (q.boxX >> 16) >> kBinShift;
+                    const uint32_t cy0 = (q.boxY & 0xFFFFu) >> kBinShift, cy1 = (q.boxY >> 16) >> kBinShift;
+                    for (uint32_t cy = cy0; cy <= cy1; ++cy)
+                        for (uint32_t cx = cx0; cx <= cx1; ++cx) {
+                            const uint32_t bin = cy * a.binsX + cx;
+                            const uint32_t k = atomicAdd(&a.binCount[bin], 1u);
+                            if (k < kBinCapacity) a.binList[(uint64_t)bin * kBinCapacity + k] = slot;
+                        }
+                } else {
+                    big = false;                                                             // queue full: drawn in place
+                }
+            }
+            // the others, in place
+            const unsigned long long smallMask = __ballot(live && !big);
+            if (smallMask) {
+                st[lane] = q;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                uint32_t* depth = a.depth;
+                for (unsigned long long mrem = smallMask; mrem; mrem &= mrem - 1ull) {
+                    const BigTriangle c = st[__builtin_ctzll(mrem)];
+                    const uint32_t bx0 = c.boxX & 0xFFFFu, by0 = c.boxY & 0xFFFFu;
+                    coverBox(c.x0, c.y0, c.d0, c.x1, c.y1, c.d1, c.x2, c.y2, c.d2, c.sgn, bx0, by0, (c.boxX >> 16) - bx0 + 1u, (c.boxY >> 16) - by0 + 1u, lane, 64u,
+                             [depth, W](uint32_t px, uint32_t py, uint32_t bits) { atomicMax(&depth[(uint64_t)py * W + px], bits); });
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                       // st is rewritten by the next 64 triangles
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                           // the LDS slice is reused by the next meshlet
         __builtin_amdgcn_wave_barrier();
