@@ -180,9 +180,10 @@ def main():
     if dist is not None:
         # one slot size for all ranks: the largest shard, every instance submitted at LOD 0
         slot_groups = max(b - a for a, b in (shard_range(spec.num_instances, p, shard_world) for p in range(shard_world))) * groups_per_instance
-        gather = NativeShardExchange(r, dist, world, rank, slot_groups, pass_slots=(0, 1),
-                                  group_capacity=spec.num_instances * groups_per_instance,
-                                  overlap=not os.environ.get("TR_NO_OVERLAP"), stage_through_host=backend != "nccl")
+        loopback = args.emulate_ranks > 1 and bool(os.environ.get("TR_EMULATE_LOOPBACK"))   # diagnostic: the unpack sees M shards
+        gather = NativeShardExchange(r, dist, shard_world if loopback else world, shard_rank if loopback else rank, slot_groups, pass_slots=(0, 1),
+                                  group_capacity=spec.num_instances * groups_per_instance + (shard_world if loopback else 0) * groups_per_instance,
+                                  overlap=not os.environ.get("TR_NO_OVERLAP"), stage_through_host=backend != "nccl", loopback=loopback)
 
     rec_hist = []
     cpu_t = [0.0, 0.0, 0.0, 0.0]                          # host time spent submitting: frame, exchange (diagnostics, stderr only)
@@ -245,7 +246,7 @@ def main():
         counts = t.cpu().numpy()
     tested_all, groups_all, visible_all = (int(x) for x in counts)
     gather_checked = None
-    if gather is not None and world == 1:
+    if gather is not None and world == 1 and not (args.emulate_ranks > 1 and os.environ.get("TR_EMULATE_LOOPBACK")):
         # 1-rank group: the gathered whole-scene lists must equal the local ones
         gather_checked = True
         for i, s_ in enumerate((0, 1)):

@@ -238,7 +238,7 @@ class NativeShardExchange:
 
     def __init__(self, renderer, dist, world: int, rank: int, slot_groups: int, pass_slots=(0, 1),
                  group_capacity: int | None = None, list_capacity: int | None = None, overlap: bool = True,
-                 stage_through_host: bool = False):
+                 stage_through_host: bool = False, loopback: bool = False):
         import ctypes as C
 
         import torch
@@ -255,7 +255,24 @@ class NativeShardExchange:
         d.list_capacity, d.overlap = self.list_capacity, int(bool(overlap))
         d.pass_slot_mask = sum(1 << s for s in self.pass_slots)
         self.comms = []
-        if stage_through_host:
+        if loopback:
+            # diagnostic (bench.py --emulate-ranks with TR_EMULATE_LOOPBACK=1): ONE process plays rank `rank` of `world`; a
+            # collective copies this rank's contribution into every slot on the device, so the unpack sees `world` shards
+            # (the volume of a real run, not its contents).
+            def fn(_user, send, recv, count, stream):
+                try:
+                    with torch.cuda.stream(torch.cuda.ExternalStream(int(stream or 0))):
+                        src = torch.as_tensor(_DevWords(int(send), int(count)), device="cuda")
+                        torch.as_tensor(_DevWords(int(recv), int(count) * self.world), device="cuda").view(self.world, int(count)).copy_(src.unsqueeze(0).expand(self.world, -1))
+                    return 0
+                except Exception as e:          # a ctypes callback cannot propagate
+                    import sys
+                    print(f"loopback all-gather failed: {e}", file=sys.stderr, flush=True)
+                    return 1
+            cb = host.ALLGATHER_FN(fn)
+            self._keep.append(cb)
+            d.slots_allgather = d.late_allgather = C.cast(cb, C.c_void_p).value
+        elif stage_through_host:
             groups = [dist.new_group(), dist.new_group()]
 
             def staged(group):
