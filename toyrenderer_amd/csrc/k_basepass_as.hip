@@ -497,28 +497,39 @@ __global__ __launch_bounds__(1024) void visScanKernel(MeshletCullArgs a)
 // batch offset + popcounts of the earlier groups of its batch + WavePrefixCountBits in its group.
 __global__ __launch_bounds__(kBlock) void visExpandKernel(MeshletCullArgs a)
 {
+    __shared__ uint2 s_mo[kWaves][kBatch];                    // per record of the wave's batch: {mask, list offset}
     const uint32_t G = groupCount(a);
     const uint32_t numBatches = (G + kBatch - 1) / kBatch;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t half = lane >> 5, sub = lane & 31u;
+    const uint32_t bit = 1u << sub, below = bit - 1u;
+    uint2* mo = s_mo[wave];
     for (uint32_t batch = blockIdx.x * kWaves + wave; batch < numBatches; batch += gridDim.x * kWaves) {
         const uint32_t g0 = batch * kBatch;
         const uint32_t mask = g0 + lane < G ? a.visMask[g0 + lane] : 0u;
         const uint32_t pc = (uint32_t)__popc(mask);
         const uint32_t exc = waveInclusiveScan(pc, lane) - pc + a.batchSum[batch];
-#pragma unroll 4
+        mo[lane] = make_uint2(mask, exc);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // lane (half, sub) looks at bit `sub` of records half, 2 + half, ...: the record's {mask, offset} is one broadcast
+        // LDS read per half-wave, the position one v_bcnt (popcount + add)
+        uint32_t value = ((g0 + half) << 5) | sub;
+#pragma unroll 8
         for (uint32_t s = 0; s < kSteps; ++s) {
-            const uint32_t r = 2 * s + half;
-            const uint32_t m = __shfl(mask, r);
-            const uint32_t off = __shfl(exc, r);
-            if (m & (1u << sub)) {
-                const uint32_t pos = off + (uint32_t)__popc(m & ((1u << sub) - 1u));
-                if (pos < a.listCapacity) a.visibleList[pos] = ((g0 + r) << 5) | sub;
+            const uint2 e = mo[2 * s + half];
+            if (e.x & bit) {
+                const uint32_t pos = e.y + (uint32_t)__popc(e.x & below);
+                if (pos < a.listCapacity) a.visibleList[pos] = value;
             }
+            value += 2u << 5;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                       // the slice is rewritten by the next batch
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Single-launch ordered compaction for SMALL passes (record capacity < 2^19: one rank's share of a sharded scene, real
