@@ -59,6 +59,7 @@ struct InstanceCullArgs
     // into cursors by the scan kernel; perm lives in the records buffer's sidecar: {valid, count, ...}
     // header (64 words) followed by one record index per group.
     uint32_t* tileCount;
+    uint32_t tileReplicas;          // kTileReplicas or kTileReplicasSmall
     uint16_t* tileOf;               // per entry
     uint32_t* permHeader;
     uint4* perm;                    // {record index, instance, lod, group offset}: the record itself, in processing order
@@ -115,7 +116,8 @@ __global__ __launch_bounds__(256) void instanceCacheKernel(const BasePassInstanc
 
 constexpr uint32_t kTilesPerAxis = 32;
 constexpr uint32_t kNumTiles = kTilesPerAxis * kTilesPerAxis;
-constexpr uint32_t kTileReplicas = 32;            // counters are replicated (blockIdx % 32) to spread the atomics
+constexpr uint32_t kTileReplicas = 32;            // counters are replicated (blockIdx % replicas) to spread the atomics: 32 for large
+constexpr uint32_t kTileReplicasSmall = 8;        // passes (781 k atomics on C3), 8 for small ones, where the scan over them is what costs
 constexpr uint32_t kPermHeaderWords = 64;
 #ifndef TR_MIN_BINNED
 #define TR_MIN_BINNED 4096
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void instanceClassifyKernel(InstanceCullArg
 
     const uint32_t g = (word & kWordSubmit) ? (word & kGroupMask) : 0u;
     if (g != 0 && n >= kMinBinnedEntries) {
-        atomicAdd(&a.tileCount[tile * kTileReplicas + (blockIdx.x % kTileReplicas)], g);   // histogram of groups per screen tile
+        atomicAdd(&a.tileCount[tile * a.tileReplicas + (blockIdx.x % a.tileReplicas)], g);   // histogram of groups per screen tile
         a.tileOf[t] = (uint16_t)tile;
     }
     const uint32_t late = word >> 31;
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void instanceClassifyKernel(InstanceCullArg
 
 // One block: exclusive scan over the per-block sums; final counters.  Tiles of 1024 entries: wave
 // scans + one LDS exchange per tile; only the blocks that had threads (device-side count) are visited.
-template <int LATE>
+template <int LATE, uint32_t REPLICAS>
 __global__ __launch_bounds__(1024) void instanceScanKernel(InstanceCullArgs a)
 {
     __shared__ uint32_t s_wg[2][16];
@@ -326,11 +328,11 @@ __global__ __launch_bounds__(1024) void instanceScanKernel(InstanceCullArgs a)
     if (n >= kMinBinnedEntries) {
         __syncthreads();
         const uint32_t lane = tid & 63u, wave = tid >> 6;
-        uint32_t rep[kTileReplicas];
+        uint32_t rep[REPLICAS];
         uint32_t c = 0;
 #pragma unroll
-        for (uint32_t i = 0; i < kTileReplicas; i += 4) {
-            const uint4 v = *reinterpret_cast<const uint4*>(&a.tileCount[tid * kTileReplicas + i]);
+        for (uint32_t i = 0; i < REPLICAS; i += 4) {
+            const uint4 v = *reinterpret_cast<const uint4*>(&a.tileCount[tid * REPLICAS + i]);
             rep[i] = v.x; rep[i + 1] = v.y; rep[i + 2] = v.z; rep[i + 3] = v.w;
             c += v.x + v.y + v.z + v.w;
         }
@@ -342,13 +344,13 @@ __global__ __launch_bounds__(1024) void instanceScanKernel(InstanceCullArgs a)
         for (uint32_t w = 0; w < wave; ++w) pre += s_w[w];
         uint32_t run = pre + inc - c;
 #pragma unroll
-        for (uint32_t i = 0; i < kTileReplicas; i += 4) {
+        for (uint32_t i = 0; i < REPLICAS; i += 4) {
             uint4 v;
             v.x = run; run += rep[i];
             v.y = run; run += rep[i + 1];
             v.z = run; run += rep[i + 2];
             v.w = run; run += rep[i + 3];
-            *reinterpret_cast<uint4*>(&a.tileCount[tid * kTileReplicas + i]) = v;
+            *reinterpret_cast<uint4*>(&a.tileCount[tid * REPLICAS + i]) = v;
         }
     }
 }
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(kBlock) void instanceEmitKernel(InstanceCullArgs a)
         a.records[off + i] = rec;
     }
     if (groups != 0 && n >= kMinBinnedEntries) {                                    // slot range in the tile-sorted order
-        const uint32_t p = atomicAdd(&a.tileCount[(uint32_t)a.tileOf[t] * kTileReplicas + (blockIdx.x % kTileReplicas)], groups);
+        const uint32_t p = atomicAdd(&a.tileCount[(uint32_t)a.tileOf[t] * a.tileReplicas + (blockIdx.x % a.tileReplicas)], groups);
         for (uint32_t i = 0; i < groups; ++i)
             if (p + i < a.permCapacity) a.perm[p + i] = make_uint4(off + i, id, lod, i * kNumThreadsPerWave);
     }
@@ -488,7 +490,8 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
     a.blockGroups = (uint32_t*)ctx.scratch((size_t)a.numBlocks * 4);
     a.blockLateSubmit = (uint64_t*)ctx.scratch((size_t)a.numBlocks * 8);
     a.bases = (uint32_t*)ctx.scratch(16);
-    a.tileCount = (uint32_t*)ctx.scratch(kNumTiles * kTileReplicas * 4);
+    a.tileReplicas = nMax >= (1u << 18) ? kTileReplicas : kTileReplicasSmall;
+    a.tileCount = (uint32_t*)ctx.scratch(kNumTiles * a.tileReplicas * 4);
     a.tileOf = (uint16_t*)ctx.scratch((size_t)nMax * 2);
     TRHIP_REQUIRE(a.word && a.localOff && a.blockGroups && a.blockLateSubmit && a.bases && a.tileCount && a.tileOf, "%s: scratch allocation failed", ctx.shaderName);
     // sidecar of the amplification buffer: header + one u32 per record slot
@@ -505,7 +508,7 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
         a.perm = (uint4*)(a.permHeader + kPermHeaderWords);
         a.permCapacity = a.maxGroups;
     }
-    rc = ctx.cl->recordClearWords(a.tileCount, kNumTiles * kTileReplicas, 0, true);   // scratch of this pass: joins the recording's first clear launch
+    rc = ctx.cl->recordClearWords(a.tileCount, kNumTiles * a.tileReplicas, 0, true);   // scratch of this pass: joins the recording's first clear launch
     if (rc != TRHIP_OK) return rc;
     // The early meshlet cull that follows this pass resolves its HZB lookups through the footprint-min table of
     // this same HZB (k_hzb.hip): bring the table up to date on the side stream while the instance pass runs.
@@ -518,7 +521,8 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
         hipLaunchKernelGGL(instanceClassifyKernel<LATE>, dim3(a.numBlocks), dim3(kBlock), 0, s, a);
         return trhip::launchStatus("instanceClassifyKernel"); });
     ctx.emit("scan", [a](hipStream_t s) {
-        hipLaunchKernelGGL(instanceScanKernel<LATE>, dim3(1), dim3(1024), 0, s, a);
+        if (a.tileReplicas == kTileReplicas) hipLaunchKernelGGL((instanceScanKernel<LATE, kTileReplicas>), dim3(1), dim3(1024), 0, s, a);
+        else hipLaunchKernelGGL((instanceScanKernel<LATE, kTileReplicasSmall>), dim3(1), dim3(1024), 0, s, a);
         return trhip::launchStatus("instanceScanKernel"); });
     const size_t scanOp = ctx.cl->ops.size() - 1;
     ctx.emit("emit", [a](hipStream_t s) {
@@ -548,7 +552,8 @@ int recordBuildLateArgs(trhip::DispatchCtx& ctx)
             fused.lateArgsOut = a;
             const size_t scanOp = note->scanOp;
             ctx.cl->ops[scanOp].fn = [fused](hipStream_t s) {
-                hipLaunchKernelGGL(instanceScanKernel<0>, dim3(1), dim3(1024), 0, s, fused);
+                if (fused.tileReplicas == kTileReplicas) hipLaunchKernelGGL((instanceScanKernel<0, kTileReplicas>), dim3(1), dim3(1024), 0, s, fused);
+                else hipLaunchKernelGGL((instanceScanKernel<0, kTileReplicasSmall>), dim3(1), dim3(1024), 0, s, fused);
                 return trhip::launchStatus("instanceScanKernel"); };
             // this dispatch's accesses (count read, arguments written) now happen in the scan command
             for (size_t i = ctx.cl->useMarks.size(); i-- > 0 && ctx.cl->useMarks[i].op >= ctx.cl->ops.size();) ctx.cl->useMarks[i].op = scanOp;
