@@ -146,21 +146,26 @@ def test_headline_config_subsample_spot_check(oracle):
         assert ref.meshletsTested[0] > 500_000 and 0 < ref.drawArgs[0][0] < ref.meshletsTested[0]
 
 
-def test_bench_rccl_gather_path_single_rank():
+@pytest.mark.parametrize("direct", [True, False])
+def test_bench_rccl_gather_path_single_rank(direct):
     """bench.py end to end on a small unique-meshlet config with the RCCL gather forced on a 1-rank
-    group: exercises device-pointer wrapping, the pack / all_gather_into_tensor / unpack pipeline on two
-    streams with double buffering, and checks the gathered whole-scene lists against the local ones."""
+    group: exercises device-pointer wrapping, the pack / all-gather / unpack pipeline on two
+    streams with double buffering, and checks the gathered whole-scene lists against the local ones.
+    direct=False: the fallback that calls the process group's all_gather_into_tensor (TR_NO_DIRECT_RCCL)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, TR_FORCE_GATHER="1")
+    if not direct:
+        env["TR_NO_DIRECT_RCCL"] = "1"
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "C3s", "--steps", "3", "--warmup", "2",
                         "--cpu-sample-instances", "4096"], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["gather_checked"] is True
+    assert ("using torch.distributed all_gather" in p.stderr) == (not direct)
     assert out["value"] > 0 and out["roofline"]["achieved"] > 0 and out["cpu_baseline"]["value"] > 0
     assert out["config"]["meshlets_tested_per_frame"] > 100_000
 

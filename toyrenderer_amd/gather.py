@@ -294,15 +294,55 @@ class NativeShardExchange:
                 return C.cast(cb, C.c_void_p).value
             d.slots_allgather, d.late_allgather = staged(groups[0]), staged(groups[1])
         else:
-            R = RcclComm.lib(torch)
-            fn_addr = C.cast(L.trhost_rccl_allgather, C.c_void_p).value
-            for _ in range(2):
-                comm = RcclComm(dist, torch, self.world, self.rank)
-                user = (C.c_void_p * 2)(C.cast(R.ncclAllGather, C.c_void_p).value, comm.comm.value)
-                self.comms.append(comm)
-                self._keep.append(user)
-            d.slots_allgather, d.slots_user = fn_addr, C.cast(self._keep[0], C.c_void_p).value
-            d.late_allgather, d.late_user = fn_addr, C.cast(self._keep[1], C.c_void_p).value
+            # Direct RCCL communicators; if any rank cannot create them (librccl not where torch keeps it, bootstrap
+            # refused, ...) EVERY rank falls back to the process group's own all-gather on device tensors -- slower
+            # (torch's stream hand-over per call) but the same data path, and said so on stderr.
+            import os
+            import sys
+            ok = 1
+            try:
+                if os.environ.get("TR_NO_DIRECT_RCCL"):
+                    raise RuntimeError("TR_NO_DIRECT_RCCL is set")
+                R = RcclComm.lib(torch)
+                fn_addr = C.cast(L.trhost_rccl_allgather, C.c_void_p).value
+                for _ in range(2):
+                    comm = RcclComm(dist, torch, self.world, self.rank)
+                    user = (C.c_void_p * 2)(C.cast(R.ncclAllGather, C.c_void_p).value, comm.comm.value)
+                    self.comms.append(comm)
+                    self._keep.append(user)
+            except Exception as e:
+                ok = 0
+                print(f"[rank {rank}] direct RCCL communicator unavailable ({e}); using torch.distributed all_gather", file=sys.stderr, flush=True)
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()):
+                d.slots_allgather, d.slots_user = fn_addr, C.cast(self._keep[0], C.c_void_p).value
+                d.late_allgather, d.late_user = fn_addr, C.cast(self._keep[1], C.c_void_p).value
+            else:
+                for c in self.comms:
+                    c.destroy()
+                self.comms, self._keep = [], []
+                groups = [dist.new_group(), dist.new_group()]
+                hand_over = [torch.cuda.Stream(), torch.cuda.Stream()]       # torch-side streams the process group is called from
+
+                def through_torch(group, mine):
+                    def fn(_user, send, recv, count, stream):
+                        try:
+                            ext = torch.cuda.ExternalStream(int(stream or 0))
+                            with torch.cuda.stream(mine):
+                                mine.wait_stream(ext)
+                                src = torch.as_tensor(_DevWords(int(send), int(count)), device="cuda")
+                                out = torch.as_tensor(_DevWords(int(recv), int(count) * self.world), device="cuda")
+                                dist.all_gather_into_tensor(out, src, group=group)
+                                ext.wait_stream(mine)
+                            return 0
+                        except Exception as e:          # a ctypes callback cannot propagate
+                            print(f"[rank {rank}] all-gather through torch.distributed failed: {e}", file=sys.stderr, flush=True)
+                            return 1
+                    cb = host.ALLGATHER_FN(fn)
+                    self._keep.append(cb)
+                    return C.cast(cb, C.c_void_p).value
+                d.slots_allgather, d.late_allgather = through_torch(groups[0], hand_over[0]), through_torch(groups[1], hand_over[1])
         host._check(L.trhost_exchange_create(C.byref(d)))
         self._L = L
 
