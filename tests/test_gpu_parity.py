@@ -439,3 +439,17 @@ def test_randomised_small_scene_sweep(dev, oracle, block):
                       frames=int(rng.integers(1, 3)))
         except AssertionError as e:
             raise AssertionError(f"case {case}: {spec} render={render} flags={flags} forced={forced} cap={cap}: {e}") from e
+
+
+def test_three_kernel_instance_pass_on_small_scenes():
+    """Small passes run classify + scan + emit as ONE launch (instanceFusedKernel); the three-kernel path then only sees
+    the full-size configs.  TRHIP_NO_FUSED_INSTANCE=1 sends the small cases of this file through it as well."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TRHIP_NO_FUSED_INSTANCE="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "all_flag or late_dispatch or group_cap or two_frames or sweep or empty or forced"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]

@@ -65,10 +65,13 @@ struct InstanceCullArgs
     uint4* perm;                    // {record index, instance, lod, group offset}: the record itself, in processing order
     uint32_t permCapacity;
     uint32_t* lateArgsOut;          // early, optional: gpuculling_CS_BuildLateCullIndirectArgs folded into the scan (recordBuildLateArgs)
+    // small passes (instanceFusedKernel): one status line per tile of 256 entries + the ticket counter, zeroed per launch
+    unsigned long long* fusedStatus;
+    uint32_t* fusedTicket;
 };
 
 // What an early recordGPUCulling leaves for a recordBuildLateArgs that follows it immediately (trhip_cmdlist_t::peephole).
-struct EarlyCullNote { InstanceCullArgs a; size_t scanOp; };
+struct EarlyCullNote { InstanceCullArgs a; size_t scanOp; bool fused; };
 
 __global__ __launch_bounds__(256) void instanceCacheKernel(const BasePassInstanceConstants* instances, uint32_t n,
                                                            const MeshData* meshData, uint32_t numMeshes, InstanceCullCache c)
@@ -387,6 +390,127 @@ __global__ __launch_bounds__(kBlock) void instanceEmitKernel(InstanceCullArgs a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Small passes (at most kFusedMaxEntries list entries: one rank's share of a sharded scene, real assets): classify, scan
+// and emit in ONE launch -- two links less in the frame's chain of dependent launches (DESIGN.md "Launch chain").  A
+// workgroup takes tiles of 256 entries in ticket order; a tile publishes its three sums (groups | late, submits) in
+// two 64-bit relaxed agent-scope atomics of its own 128-byte status line and then adds up the sums of ALL its
+// predecessors (at most 511: two per thread, one round trip) -- a tile only waits for tiles with smaller tickets, which
+// are held by workgroups already running.  Same canonical order as the three-kernel path; no tile binning (the
+// processing order of the meshlet pass stays canonical: measured a wash at this size).
+constexpr uint32_t kFusedMaxEntries = 1u << 17;
+constexpr uint32_t kFusedMaxTiles = kFusedMaxEntries / kBlock;       // 512
+constexpr uint32_t kFusedStatusStride = 16;                          // 64-bit words per tile: one 128-byte line
+constexpr unsigned long long kFusedFlag = 1ull << 63, kFusedPoison = 1ull << 60;
+
+template <int LATE>
+__global__ __launch_bounds__(kBlock) void instanceFusedKernel(InstanceCullArgs a)
+{
+    __shared__ uint32_t s_waveG[kBlock / 64], s_waveL[kBlock / 64], s_waveS[kBlock / 64];
+    __shared__ unsigned long long s_preG[kBlock / 64], s_preLS[kBlock / 64];
+    __shared__ uint32_t s_tile;
+    const uint32_t n = threadCount<LATE>(a);
+    const uint32_t numTiles = (n + kBlock - 1) / kBlock < a.numBlocks ? (n + kBlock - 1) / kBlock : a.numBlocks;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // the counters the pass continues from: read by every workgroup before any tile can finish the pass and rewrite them
+    const uint32_t baseX = a.dispatchArgs[0];
+    const uint32_t baseLate = LATE ? 0u : *a.lateCount;
+    for (;;) {
+        __syncthreads();                                                             // s_tile and the LDS sums are reused
+        if (tid == 0) s_tile = atomicAdd(a.fusedTicket, 1u);
+        __syncthreads();
+        const uint32_t tile = s_tile;
+        if (tile >= numTiles && !(tile == 0 && numTiles == 0)) return;
+        const uint32_t t = tile * kBlock + tid;
+        uint32_t word = 0, tileUnused = 0;
+        if (t < n) word = classify<LATE>(a, a.ids[t], &tileUnused);
+        const uint32_t g = (word & kWordSubmit) ? (word & kGroupMask) : 0u;
+        const uint32_t late = word >> 31;
+        const uint32_t submit = (word >> 30) & 1u;
+        const uint32_t incG = waveInclusiveScan(g, lane);
+        const uint32_t incL = waveInclusiveScan(late, lane);
+        const uint32_t cntS = (uint32_t)__popcll(__ballot(submit != 0));
+        if (lane == 63) { s_waveG[wave] = incG; s_waveL[wave] = incL; s_waveS[wave] = cntS; }
+        __syncthreads();
+        uint32_t baseG = 0, baseL = 0, totG = 0, totL = 0, totS = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kBlock / 64; ++w) {
+            if (w < wave) { baseG += s_waveG[w]; baseL += s_waveL[w]; }
+            totG += s_waveG[w]; totL += s_waveL[w]; totS += s_waveS[w];
+        }
+        const uint32_t localOff = late ? (baseL + incL - late) : (baseG + incG - g);
+        // ---- publish this tile's sums, add up the predecessors' -----------------------------------------------------
+        unsigned long long* line = a.fusedStatus + (uint64_t)tile * kFusedStatusStride;
+        if (tid == 0 && numTiles != 0) {
+            __hip_atomic_store(&line[0], kFusedFlag | (unsigned long long)totG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&line[1], kFusedFlag | ((unsigned long long)totS << 32) | (unsigned long long)totL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned long long sumG = 0, sumLS = 0;
+        for (uint32_t j = tid; j < tile; j += kBlock) {                              // at most two predecessors per thread
+            const unsigned long long* pl = a.fusedStatus + (uint64_t)j * kFusedStatusStride;
+            unsigned long long v0 = 0, v1 = 0;
+            uint32_t spins = 0;
+            for (;;) {
+                v0 = __hip_atomic_load(&pl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v1 = __hip_atomic_load(&pl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v0 & v1 & kFusedFlag) != 0ull) { v0 &= ~kFusedFlag; v1 &= ~kFusedFlag; break; }
+                if (++spins > (1u << 22)) { v0 = kFusedPoison; v1 = 0; break; }      // never seen: a wrong count fails parity, a hang would take the GPU down
+                __builtin_amdgcn_s_sleep(1);
+            }
+            sumG += v0; sumLS += v1;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { sumG += __shfl_xor(sumG, d); sumLS += __shfl_xor(sumLS, d); }
+        if (lane == 0) { s_preG[wave] = sumG; s_preLS[wave] = sumLS; }
+        __syncthreads();
+        unsigned long long preG = 0, preLS = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kBlock / 64; ++w) { preG += s_preG[w]; preLS += s_preLS[w]; }
+        const uint32_t prefixG = (uint32_t)preG, prefixL = (uint32_t)preLS;           // (a poisoned sum shows up in X below)
+        // ---- emit (gpuculling.hlsl:60-84, :162-167), as instanceEmitKernel ---------------------------------------------
+        if (t < n) {
+            if (word & kWordLate) {
+                a.lateIds[baseLate + prefixL + localOff] = a.ids[t];
+            } else if (word & kWordSubmit) {
+                const uint32_t groups = word & kGroupMask;
+                const uint32_t lod = (word >> 27) & 7u;
+                const uint32_t off = baseX + prefixG + localOff;                         // :65
+                if (off + groups >= a.maxGroups) {                                       // :69-74 (Q2)
+                    if (groups != 0 && off < a.maxGroups && a.argsWords > 3) a.dispatchArgs[3] = off;
+                } else {
+                    const uint32_t id = a.ids[t];
+                    for (uint32_t i = 0; i < groups; ++i) {                              // :76-84
+                        MeshletAmplificationData rec = { id, lod, i * kNumThreadsPerWave };
+                        a.records[off + i] = rec;
+                    }
+                }
+            }
+        }
+        // ---- the last tile closes the pass (what instanceScanKernel's thread 0 does) -----------------------------------
+        if (tid == 0 && (tile == numTiles - 1u || numTiles == 0)) {
+            const unsigned long long allG = preG + totG;
+            const uint32_t allL = prefixL + totL, allS = (uint32_t)(preLS >> 32) + totS;
+            const uint32_t X = (allG >> 40) ? 0xFFFFFFFFu : baseX + (uint32_t)allG;      // poisoned -> an impossible count
+            a.bases[0] = baseX;
+            a.bases[1] = baseLate;
+            a.dispatchArgs[0] = X;                                                       // :65 (counter still counts drops, Q2)
+            if (allS != 0) { a.dispatchArgs[1] = 1; a.dispatchArgs[2] = 1; }            // :66-67
+            // valid records: X unless an instance is dropped at the capacity -- then that instance writes its offset
+            // above (it exists iff X reaches the capacity from below it)
+            if (a.argsWords > 3 && (X < a.maxGroups || baseX >= a.maxGroups)) a.dispatchArgs[3] = X;
+            if (!LATE) {
+                const uint32_t lateTotal = baseLate + allL;
+                *a.lateCount = lateTotal;                                                // :165
+                if (a.lateArgsOut) { a.lateArgsOut[0] = (lateTotal + 63u) / 64u; a.lateArgsOut[1] = 1; a.lateArgsOut[2] = 1; }
+            }
+            a.permHeader[0] = 0u;                                                        // canonical processing order
+            a.permHeader[1] = X;
+        }
+        if (numTiles == 0) return;
+    }
+}
+
 __global__ void buildLateCullIndirectArgsKernel(const uint32_t* count, uint32_t* args)
 {
     args[0] = (count[0] + 63u) / 64u;                                               // gpuculling.hlsl:192 (Q1)
@@ -517,6 +641,22 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
         if (rc != TRHIP_OK) return rc;
     }
 
+    static const bool noFused = getenv("TRHIP_NO_FUSED_INSTANCE") != nullptr;          // tests: the three-kernel path on small passes
+    if (nMax <= kFusedMaxEntries && !noFused) {
+        const size_t words = (size_t)kFusedMaxTiles * kFusedStatusStride * 2 + 4;
+        uint32_t* mem = (uint32_t*)ctx.scratch(words * 4);
+        TRHIP_REQUIRE(mem, "%s: scratch allocation failed", ctx.shaderName);
+        rc = ctx.cl->recordClearWords(mem, words, 0, true);
+        if (rc != TRHIP_OK) return rc;
+        a.fusedStatus = (unsigned long long*)mem;
+        a.fusedTicket = mem + kFusedMaxTiles * kFusedStatusStride * 2;
+        ctx.emit("fused", [a](hipStream_t s) {
+            hipLaunchKernelGGL(instanceFusedKernel<LATE>, dim3(a.numBlocks), dim3(kBlock), 0, s, a);
+            return trhip::launchStatus("instanceFusedKernel"); });
+        if (!LATE && occlusion) ctx.cl->peephole = { ctx.cl->ops.size() - 1, "gpuculling_early", std::make_shared<EarlyCullNote>(EarlyCullNote{ a, ctx.cl->ops.size() - 1, true }) };
+        return TRHIP_OK;
+    }
+
     ctx.emit("classify", [a](hipStream_t s) {
         hipLaunchKernelGGL(instanceClassifyKernel<LATE>, dim3(a.numBlocks), dim3(kBlock), 0, s, a);
         return trhip::launchStatus("instanceClassifyKernel"); });
@@ -528,7 +668,7 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
     ctx.emit("emit", [a](hipStream_t s) {
         hipLaunchKernelGGL(instanceEmitKernel<LATE>, dim3(a.numBlocks), dim3(kBlock), 0, s, a);
         return trhip::launchStatus("instanceEmitKernel"); });
-    if (!LATE && occlusion) ctx.cl->peephole = { ctx.cl->ops.size() - 1, "gpuculling_early", std::make_shared<EarlyCullNote>(EarlyCullNote{ a, scanOp }) };
+    if (!LATE && occlusion) ctx.cl->peephole = { ctx.cl->ops.size() - 1, "gpuculling_early", std::make_shared<EarlyCullNote>(EarlyCullNote{ a, scanOp, false }) };
     return TRHIP_OK;
 }
 
@@ -551,7 +691,11 @@ int recordBuildLateArgs(trhip::DispatchCtx& ctx)
             InstanceCullArgs fused = note->a;
             fused.lateArgsOut = a;
             const size_t scanOp = note->scanOp;
-            ctx.cl->ops[scanOp].fn = [fused](hipStream_t s) {
+            if (note->fused)
+                ctx.cl->ops[scanOp].fn = [fused](hipStream_t s) {
+                    hipLaunchKernelGGL(instanceFusedKernel<0>, dim3(fused.numBlocks), dim3(kBlock), 0, s, fused);
+                    return trhip::launchStatus("instanceFusedKernel"); };
+            else ctx.cl->ops[scanOp].fn = [fused](hipStream_t s) {
                 if (fused.tileReplicas == kTileReplicas) hipLaunchKernelGGL((instanceScanKernel<0, kTileReplicas>), dim3(1), dim3(1024), 0, s, fused);
                 else hipLaunchKernelGGL((instanceScanKernel<0, kTileReplicasSmall>), dim3(1), dim3(1024), 0, s, fused);
                 return trhip::launchStatus("instanceScanKernel"); };
