@@ -8,8 +8,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 nframes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 k = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?"), r.get("Stream_Id", "?")) for r in rows]
 k.sort()
-# a frame starts at each instanceClassifyKernel<0>
-starts = [i for i, x in enumerate(k) if "instanceClassifyKernel<0>" in x[2] or "instanceClassifyKernelILi0" in x[2]]
+# a frame starts at each early instance pass (instanceClassifyKernel<0>, or instanceFusedKernel<0> for small passes)
+starts = [i for i, x in enumerate(k) if any(t in x[2] for t in ("instanceClassifyKernel<0>", "instanceClassifyKernelILi0", "instanceFusedKernel<0>", "instanceFusedKernelILi0"))]
 if len(starts) < nframes + 1:
     print("not enough frames", len(starts)); sys.exit(0)
 a, b = starts[-nframes - 1], starts[-1]
