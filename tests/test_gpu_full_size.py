@@ -106,6 +106,44 @@ def test_c3_one_rank_share_of_eight(oracle):
         _properties(got, s)
 
 
+def test_c3_rank_share_is_stable_over_many_frames(oracle):
+    """The small-pass kernels chain their tiles through tickets and status words (instanceFusedKernel, visCompactKernel):
+    200 frames of the C3r share with a static camera, outputs downloaded every 20th frame -- every word identical to the
+    oracle's steady state each time (an intermittent ordering bug would show as a differing frame)."""
+    import hashlib
+    from toyrenderer_amd import host
+    spec = synth.config_spec("C3r")
+    cap = spec.num_instances * ((spec.meshlets_lod0 + 31) // 32) + 1
+    view = synth.make_view(eye=(0.0, 0.0, 0.0), prev_eye=(0.05, 0.0, 0.1), prev_yaw=0.002)
+    scene = synth.make_scene(spec)
+    depth = synth.gen_depth(view, 200)
+    hzb = oracle.HzbTexture(*view.hzb_dims)
+    ref = None
+    for _ in range(3):                                       # steady state of the HZB feedback
+        ref = oracle.frame(scene.as_oracle(), view.as_dict(), hzb, depth, cullingFlags=7, maxGroups=cap, record_capacity=cap, threads=16)
+
+    def digest(res):
+        h = hashlib.sha1()
+        for s_ in (0, 1):
+            for k in ("records", "visMask", "visibleList", "drawArgs", "dispatchArgs"):
+                h.update(np.ascontiguousarray(res[s_][k]).tobytes())
+        return h.hexdigest()
+    want = digest({s_: dict(records=ref.records[s_], visMask=ref.visMask[s_], visibleList=ref.visibleList[s_], drawArgs=ref.drawArgs[s_],
+                            dispatchArgs=ref.dispatchArgs[s_]) for s_ in (0, 1)})
+    r = host.Renderer(render=(view.renderW, view.renderH), max_groups=cap, max_transient_bytes=8 << 30)
+    try:
+        r.load_scene(scene.instances, scene.meshData, scene.meshlets, scene.opaqueIds, scene.alphaMaskIds)
+        r.set_culling(7)
+        r.upload_depth(depth)
+        for frame in range(200):
+            r.set_camera(view)
+            r.frame()
+            if frame >= 19 and frame % 20 == 19:
+                assert digest(r.results()) == want, f"frame {frame} differs from the steady state"
+    finally:
+        r.shutdown()
+
+
 def test_c2_without_the_side_stream():
     """The same C2 frames with the back end's side stream switched off (TRHIP_NO_SIDE_STREAM=1: list build and
     footprint-table rebuild run in order on the main stream) -- the overlap machinery must not be what makes
