@@ -851,7 +851,7 @@ int recordASMain(trhip::DispatchCtx& ctx)
     // LATE_CULL=1 follows an HZB rebuild and covers only what the early phase rejected: texel path, no table.
     // Small passes (capacity below 2^19 groups) also take the texel path: the table rebuild is a fixed ~20 us per
     // frame on the side stream and pays off only when the pass is long (same rule in k_gpuculling.hip).
-    const bool useTable = occlusion && ctx.variant == 0 && records->byteSize / sizeof(MeshletAmplificationData) >= (1u << 19);
+    const bool useTable = occlusion && ctx.variant == 0 && records->byteSize / sizeof(MeshletAmplificationData) >= trhip::tableMinGroups();
     int rc = TRHIP_OK;
     {
         memset(&a.hzb, 0, sizeof a.hzb);

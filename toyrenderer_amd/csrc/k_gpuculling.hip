@@ -636,7 +636,7 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
     if (rc != TRHIP_OK) return rc;
     // The early meshlet cull that follows this pass resolves its HZB lookups through the footprint-min table of
     // this same HZB (k_hzb.hip): bring the table up to date on the side stream while the instance pass runs.
-    if (!LATE && occlusion && a.maxGroups >= (1u << 19)) {                         // the rule of recordASMain (k_basepass_as.hip)
+    if (!LATE && occlusion && a.maxGroups >= trhip::tableMinGroups()) {                 // the rule of recordASMain (k_basepass_as.hip)
         rc = trhip::hzbQuadEmitBuild(ctx, hzb);
         if (rc != TRHIP_OK) return rc;
     }

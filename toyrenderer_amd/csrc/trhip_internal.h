@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -268,6 +269,14 @@ int hzbQuadLaunchBuild(trhip_texture_t* tex, hipStream_t s);
 // `s` unless it is current -- called while commands are submitted, so every earlier write is counted.
 int instanceCacheEnsure(trhip_buffer_t* instances);
 int instanceCacheLaunchBuild(trhip_buffer_t* instances, trhip_buffer_t* meshData, hipStream_t s);
+
+// Record capacity (groups) from which the early meshlet cull resolves its HZB lookups through the footprint-min table
+// (rebuilt per frame on the side stream: a fixed ~20 us) instead of the texels.  TRHIP_TABLE_MIN_GROUPS overrides (tuning).
+inline uint32_t tableMinGroups()
+{
+    static const uint32_t v = [] { const char* e = getenv("TRHIP_TABLE_MIN_GROUPS"); return e ? (uint32_t)strtoul(e, nullptr, 0) : (1u << 19); }();
+    return v;
+}
 
 using RecordFn = int (*)(DispatchCtx&);
 void registerShader(const char* name, RecordFn fn, int variant);
