@@ -34,6 +34,7 @@ from toyrenderer_amd import interop as I  # noqa: E402
 from toyrenderer_amd import synth  # noqa: E402
 from toyrenderer_amd.gather import shard_range  # noqa: E402
 
+MEASURED_STREAM_GBS = 6300.0      # tools/membw.hip on MI355X: 6.1-6.4 TB/s for every access pattern (profiles/r1/membw_calibration.txt)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 DOMINANT = "basepass_AS_Main LATE_CULL=0#cull"
 
@@ -106,8 +107,20 @@ def cpu_baseline(spec: synth.SceneSpec, view, depth, sample_instances: int, thre
         times.append(time.perf_counter() - t)
         tested = int(ref.meshletsTested.sum())
     dt = sorted(times)[1]
-    return dict(value=tested / dt / 1e9, unit="Gmeshlets/s", cores=threads, kind="port",
-                sample=f"first {n} instances ({total} meshlets in scene, {tested} tested/frame) of the same scene, full 2-phase frame incl. 2 HZB builds, median of 3, {dt * 1e3:.1f} ms/frame")
+    out = dict(value=tested / dt / 1e9, unit="Gmeshlets/s", cores=threads, kind="port",
+               sample=f"first {n} instances ({total} meshlets in scene, {tested} tested/frame) of the same scene, full 2-phase frame incl. 2 HZB builds, median of 3, {dt * 1e3:.1f} ms/frame")
+    # the same oracle on ONE thread (SURVEY 8d asks for both), on the first 65 536 instances so that it stays a few seconds
+    n1 = min(n, 65536)
+    if n1 == n or n1 % spec.chunk_meshes == 0:
+        sc1 = dict(scene, instances=inst[:n1], opaqueIds=np.arange(n1, dtype=np.uint32))
+        hzb1 = pyoracle.HzbTexture(*view.hzb_dims)
+        hzb1.build_from_depth(depth)
+        t = time.perf_counter()
+        ref1 = pyoracle.frame(sc1, view.as_dict(), hzb1, depth, cullingFlags=7, maxGroups=1 << 27, threads=1, record_capacity=n1 * ((spec.meshlets_lod0 + 31) // 32) + 1)
+        dt1 = time.perf_counter() - t
+        out["single_thread"] = dict(value=int(ref1.meshletsTested.sum()) / dt1 / 1e9, unit="Gmeshlets/s",
+                                    sample=f"first {n1} instances, one frame, {dt1 * 1e3:.0f} ms")
+    return out
 
 
 def main():
@@ -305,6 +318,8 @@ def main():
             pass
         roofline = dict(bound="hbm", kernel=DOMINANT, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, avg_launch_ms=round(avg_ms, 4),
+                        # against what a streaming-read kernel reaches on this part (tools/membw.hip, profiles/r1/membw_calibration.txt)
+                        frac_of_measured_stream=round(achieved / MEASURED_STREAM_GBS, 4), measured_stream_peak=MEASURED_STREAM_GBS,
                         algorithmic_bytes_per_launch=int(alg_bytes), meshlets_per_launch=int(t0_tested),
                         per_kernel_ms={k: round(v[1] / v[0], 4) for k, v in prof.items()})
 
