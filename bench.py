@@ -139,6 +139,12 @@ def main():
                          "the printed line is NOT a bench result")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process has made no GPU call yet (no torch import, no
+        # libtrhip), so it may start the ranks itself -- as a CHILD process (never exec: under rocprofv3 the profiler's
+        # preload has already initialised the GPU), relay the children's output and leave with their exit code.
+        sys.exit(self_launch(args.gpus))
+
     # The driver parses ONE JSON line from stdout; RCCL prints its version banner there.  Everything
     # else goes to stderr: fd 1 is pointed at fd 2 and the JSON line is written to the saved fd.
     sys.stdout.flush()
@@ -343,6 +349,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         out["lists_digest"] = lists_digest
+        out["collective"] = gather.collective if gather is not None else None     # "rccl-direct" | "pg" | "host-staged" | "loopback"
         if args.emulate_ranks > 1:
             out["metric"] = f"DIAGNOSTIC (rank 0 of {args.emulate_ranks} emulated on one GPU) - not a bench result"
         if gather_checked is not None:
@@ -356,6 +363,23 @@ def main():
     r.shutdown()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def self_launch(n: int) -> int:
+    """Start `n` ranks of this script through torch.distributed.run as a child process (rendezvous on 127.0.0.1, a free
+    port), let its stdout (rank 0's one JSON line) and stderr pass straight through, return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_threads() // n)))
+    log(f"[bench] --gpus {n} without WORLD_SIZE: launching {n} ranks: {' '.join(cmd)}")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def host_threads() -> int:

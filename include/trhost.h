@@ -83,6 +83,8 @@ typedef struct {
 /* slot: 0 early-opaque, 1 late-opaque, 2 early-alpha-mask, 3 late-alpha-mask */
 int  trhost_pass_buffers(uint32_t slot, trhost_pass_buffers_t* out);
 int  trhost_instance_buffer(void** buffer);
+/* Lengths of this process' opaque / alpha-mask id lists (Scene.cpp:282-362). */
+int  trhost_scene_list_sizes(uint32_t* num_opaque, uint32_t* num_alpha_mask);
 void* trhost_device(void);     /* the trhip_device in use                                           */
 
 /* Multi-GPU (one process per GPU, instance list sharded; not in the reference).  When set, fn(user, hip_stream,
@@ -105,6 +107,7 @@ int  trhost_set_shard_late_exchange(trhost_shard_late_fn fn, void* user);
  * trhost_rccl_allgather is the ready-made binding: user = void*[2] { address of ncclAllGather, the ncclComm_t }. */
 typedef int (*trhost_allgather_fn)(void* user, const void* send, void* recv, uint64_t count_words, void* hip_stream);
 int  trhost_rccl_allgather(void* user, const void* send, void* recv, uint64_t count_words, void* hip_stream);
+int  trhost_rccl_allreduce_max_u32(void* user, void* words, uint64_t count_words, void* hip_stream);   /* user = void*[2] { address of ncclAllReduce, the ncclComm_t } */
 typedef struct trhost_exchange_desc {
     uint32_t world, rank;
     uint32_t slot_groups;            /* groups one rank's shard slot holds (the same on every rank)                 */
@@ -114,6 +117,17 @@ typedef struct trhost_exchange_desc {
     int      overlap;                /* 1: gather + unpack on their own stream, overlapping the next frame          */
     trhost_allgather_fn slots_allgather; void* slots_user;     /* shard slots, once per frame                       */
     trhost_allgather_fn late_allgather;  void* late_user;      /* late-list lengths, inside the frame (1 word)      */
+    /* bit 0: SOME rank holds opaque ids, bit 1: some rank holds alpha-mask ids (an all-reduce of trhost_scene_list_sizes
+     * at set-up).  Every rank posts the in-frame late-count collective of exactly these buckets, whether its own
+     * list is empty or not (an empty list contributes 0), so the collectives match on all ranks.  0 = this rank's
+     * own lists (only right when every rank holds the same kinds of lists). */
+    uint32_t list_presence_mask;
+    /* 1: every rank rasterises only its shard's visible meshlets (trhost_set_raster_depth), so before each
+     * GenerateHZB the depth buffers are combined across ranks with `depth_allreduce_max` (element-wise MAX of the
+     * reverse-Z depth words; positive floats order like their bit patterns).  Without the callback the combination
+     * exchange + raster depth is rejected: per-rank HZBs would make the late and next-frame culls diverge from the
+     * single-GPU frame. */
+    int (*depth_allreduce_max)(void* user, void* depth_words, uint64_t count_words, void* hip_stream); void* depth_user;
 } trhost_exchange_desc;
 int  trhost_exchange_create(const trhost_exchange_desc* desc);   /* also installs the in-frame late-count hook      */
 int  trhost_exchange_run(void);                                  /* after trhost_frame: pack, gather, unpack (async) */

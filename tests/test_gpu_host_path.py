@@ -218,16 +218,53 @@ def test_ranks_sharing_one_gpu_equal_one_rank(world):
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common], capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     d1 = json.loads(one.stdout.strip().splitlines()[-1])
-    env = dict(os.environ, TR_DIST_BACKEND="gloo")
-    port = 29600 + os.getpid() % 300 + world
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), *common],
+    # `python bench.py --gpus N` with no launcher around it (the form the driver uses): bench.py starts its own ranks
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["TR_DIST_BACKEND"] = "gloo"
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), *common],
                          env=env, capture_output=True, text=True, timeout=900)
     assert two.returncode == 0, two.stderr[-3000:]
     d2 = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert d2["n_gpus"] == world and d2["config"]["meshlets_tested_per_frame"] == d1["config"]["meshlets_tested_per_frame"]
     assert d2["config"]["visible_per_frame"] == d1["config"]["visible_per_frame"]
     assert d2["lists_digest"] == d1["lists_digest"], "multi-rank whole-scene lists differ from the 1-rank lists"
+    assert d2["collective"] == "host-staged" and d1["collective"] is None
+
+
+def _run_ranks(world, mode, tmp_path, extra_env=None):
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(extra_env or {})
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "tests", "mr_host_ranks.py"), mode, str(tmp_path)],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    return p.stdout
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_with_different_kinds_of_lists(world, tmp_path):
+    """the last rank holds every alpha-mask id and no opaque id, the others only opaque ids.  All ranks post the
+    same in-frame late-count collectives (a rank without a list contributes 0); whole-scene results == the oracle's frame."""
+    out = _run_ranks(world, "uneven", tmp_path)
+    assert out.count("uneven: ok") == world
+
+
+def test_sharded_raster_depth_equals_single_gpu(tmp_path):
+    """with self-rasterised depth every rank draws only its shard; the depth buffers are MAX-combined across the
+    ranks before each HZB build, so lists, depth and HZB equal the single-GPU frame -- and without the reduction the
+    combination is rejected."""
+    out = _run_ranks(2, "raster", tmp_path)
+    assert out.count("raster: ok") == 2
+    out = _run_ranks(2, "raster", tmp_path, {"TR_TEST_NO_DEPTH_REDUCE": "1"})
+    assert out.count("rejected as expected") == 2
 
 
 @pytest.mark.parametrize("block", range(2))

@@ -33,7 +33,25 @@ RenderGraph::ResourceHandle g_DepthStencilBufferRDGTextureHandle;            // 
 // Multi-GPU hook (not in the reference): see trhost.h, trhost_set_shard_late_exchange.
 namespace
 {
-struct { ShardLateFn fn = nullptr; void* user = nullptr; } g_ShardLateExchange;
+struct { ShardLateFn fn = nullptr; void* user = nullptr; uint32_t presence = 0; ShardDepthFn depthFn = nullptr; void* depthUser = nullptr; } g_ShardLateExchange;
+struct ShardDepthCall { void* words = nullptr; uint64_t count = 0; };
+ShardDepthCall g_ShardDepthCall;
+std::string g_ShardDepthError;
+
+void ShardDepthTrampoline(void* user, void* hipStream)
+{
+    const ShardDepthCall* c = (const ShardDepthCall*)user;
+    if (g_ShardLateExchange.depthFn && g_ShardLateExchange.depthFn(g_ShardLateExchange.depthUser, c->words, c->count, hipStream) != 0)
+        g_ShardDepthError = "depth all-reduce (MAX) across ranks failed";
+}
+
+// Does SOME rank hold ids of this bucket (0 opaque, 1 alpha mask)?  Without an exchange: this rank's own list.
+bool BucketPresentAnywhere(bool bAlphaMaskPrimitives)
+{
+    const bool local = bAlphaMaskPrimitives ? !g_Scene->m_AlphaMaskPrimitiveIDs.empty() : !g_Scene->m_OpaquePrimitiveIDs.empty();
+    if (!g_ShardLateExchange.fn || g_ShardLateExchange.presence == 0) return local;
+    return local || ((g_ShardLateExchange.presence >> (bAlphaMaskPrimitives ? 1 : 0)) & 1u);
+}
 struct ShardLateCall { nvrhi::BufferHandle info; void* lateCount = nullptr; void* infoPtr = nullptr; int bucket = 0; };
 ShardLateCall g_ShardLateCalls[2];                                           // opaque, alpha mask
 
@@ -62,10 +80,13 @@ ShardLateCall& PrepareShardLateCall(bool bAlphaMaskPrimitives, nvrhi::IBuffer* l
 }
 }
 
-void SetShardLateExchange(ShardLateFn fn, void* user)
+void SetShardLateExchange(ShardLateFn fn, void* user, uint32_t listPresenceMask, ShardDepthFn depthFn, void* depthUser)
 {
     g_ShardLateExchange.fn = fn;
     g_ShardLateExchange.user = user;
+    g_ShardLateExchange.presence = fn ? listPresenceMask : 0;
+    g_ShardLateExchange.depthFn = fn ? depthFn : nullptr;
+    g_ShardLateExchange.depthUser = fn ? depthUser : nullptr;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -165,7 +186,9 @@ public:
         m_bDoMeshletConeCulling = g_Scene->m_bEnableMeshletConeCulling;
 
         const uint32_t maxGroups = g_Graphic.m_MaxMeshletGroups;              // kMaxThreadGroupsPerDimension in the reference (:237)
-        m_NumSlotsThisFrame = g_Scene->m_AlphaMaskPrimitiveIDs.empty() ? 2u : (uint32_t)kNumPassSlots;
+        // multi-GPU: a rank without alpha-mask ids still walks the alpha-mask passes when another rank has some (it posts
+        // the in-frame collectives with a zero count, see GPUCulling)
+        m_NumSlotsThisFrame = BucketPresentAnywhere(true) ? (uint32_t)kNumPassSlots : 2u;
         for (uint32_t slot = 0; slot < m_NumSlotsThisFrame; ++slot) {
             {
                 nvrhi::BufferDesc desc;                                       // :235-243
@@ -250,7 +273,21 @@ public:
         PROFILE_GPU_SCOPED(commandList, "GPU Culling");                       // :306
 
         const uint32_t nbInstances = (uint32_t)(bAlphaMaskPrimitives ? g_Scene->m_AlphaMaskPrimitiveIDs.size() : g_Scene->m_OpaquePrimitiveIDs.size());
-        if (nbInstances == 0) return;                                         // :310-314
+        if (nbInstances == 0) {                                               // :310-314
+            // multi-GPU: whether a rank joins the in-frame late-count collective must not depend on rank-local state.  A
+            // rank whose list of this bucket is empty while another rank's is not posts both hook phases with a late
+            // count of 0 and skips only the dispatches.
+            if (g_ShardLateExchange.fn && m_bDoOcclusionCulling && BucketPresentAnywhere(bAlphaMaskPrimitives)) {
+                nvrhi::BufferHandle lateCount = renderGraph.GetBuffer(m_LateCullInstanceCountBufferRDGBufferHandle);
+                if (!bLateCull) {
+                    commandList->clearBufferUInt(lateCount, 0);
+                    commandList->hostCallback(&ShardLateTrampoline<0>, &PrepareShardLateCall(bAlphaMaskPrimitives, lateCount.Get()));
+                } else {
+                    commandList->hostCallback(&ShardLateTrampoline<1>, &PrepareShardLateCall(bAlphaMaskPrimitives, lateCount.Get()));
+                }
+            }
+            return;
+        }
 
         nvrhi::BufferHandle meshletAmplificationDataBuffer = renderGraph.GetBuffer(m_MeshletAmplificationDataBufferRDGBufferHandle[slot]);
         nvrhi::BufferHandle meshletDispatchArgumentsBuffer = renderGraph.GetBuffer(m_MeshletDispatchArgumentsBufferRDGBufferHandle[slot]);
@@ -440,6 +477,17 @@ public:
         passParameters.m_bDownsampleMax = !GraphicConstants::kInversedDepthBuffer;
 
         nvrhi::TextureHandle depthStencilBuffer = params.m_DepthBuffer;       // :519
+
+        if (g_Scene->m_bRasterDepth && g_ShardLateExchange.fn) {
+            // multi-GPU with self-rasterised depth: each rank drew only its shard's visible meshlets; the HZB every rank
+            // builds must come from the whole scene's depth = element-wise MAX (reverse-Z) over the ranks.
+            if (!g_ShardDepthError.empty()) { std::string e; e.swap(g_ShardDepthError); throw nvrhi::Error(e); }
+            if (!g_ShardLateExchange.depthFn)
+                throw nvrhi::Error("raster depth + shard exchange needs trhost_exchange_desc.depth_allreduce_max: per-rank depth buffers would give per-rank HZBs");
+            g_ShardDepthCall.words = trhip_texture_device_ptr(depthStencilBuffer->native());
+            g_ShardDepthCall.count = (uint64_t)depthStencilBuffer->getDesc().width * depthStencilBuffer->getDesc().height;
+            commandList->hostCallback(&ShardDepthTrampoline, &g_ShardDepthCall);
+        }
 
         nvrhi::BindingSetDesc bindingSetDesc;                                 // :521-527
         bindingSetDesc.bindings = {

@@ -223,7 +223,7 @@ void ShardExchangeCreate(const trhost_exchange_desc& d)
             x.args[s] = makeBuffer(x.commDev, 32, "AllArgs");
         }
     for (int b = 0; b < 2; ++b) recordUnpack(x, b);
-    SetShardLateExchange(&lateHook, &x);
+    SetShardLateExchange(&lateHook, &x, d.list_presence_mask, d.depth_allreduce_max, d.depth_user);
 }
 
 void ShardExchangeRun()
@@ -260,6 +260,15 @@ void ShardExchangeOutputs(uint32_t slot, void** records, void** masks, void** li
 }
 
 void ShardExchangeDestroy() { destroy(); }
+
+// Ready-made binding of trhost_exchange_desc.depth_allreduce_max to RCCL: user = { address of ncclAllReduce, ncclComm_t }.
+// In place, ncclUint32 + ncclMax: reverse-Z depths are non-negative floats, which order like their bit patterns.
+extern "C" int trhost_rccl_allreduce_max_u32(void* user, void* words, uint64_t countWords, void* hipStream)
+{
+    using AllReduce = int (*)(const void*, void*, size_t, int, int, void*, void*);
+    void** u = (void**)user;
+    return ((AllReduce)u[0])(words, words, (size_t)countWords, 3 /* ncclUint32 */, 2 /* ncclMax */, u[1], hipStream);
+}
 
 // Ready-made binding of trhost_allgather_fn to RCCL: user = { address of ncclAllGather, ncclComm_t }.
 extern "C" int trhost_rccl_allgather(void* user, const void* send, void* recv, uint64_t countWords, void* hipStream)

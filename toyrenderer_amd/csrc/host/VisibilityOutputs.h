@@ -23,7 +23,11 @@ void ReleaseVisibilityPassBuffers();
 // Multi-GPU (instance list sharded over ranks; trhost.h trhost_set_shard_late_exchange): called while
 // the frame is submitted: after each early instance cull (phase 0) and before each late one (phase 1).
 using ShardLateFn = void (*)(void* user, void* hipStream, void* lateCount, void* shardInfo, int bucket, int phase);
-void SetShardLateExchange(ShardLateFn fn, void* user);
+// listPresenceMask: bit 0 = some rank holds opaque ids, bit 1 = some rank holds alpha-mask ids (0: this rank's own lists);
+// every rank posts the in-frame collective of exactly those buckets.  depthFn (may be null): element-wise MAX of the depth
+// words over all ranks, enqueued on hipStream -- required when the frame rasterises its own depth (m_bRasterDepth).
+using ShardDepthFn = int (*)(void* user, void* depthWords, uint64_t countWords, void* hipStream);
+void SetShardLateExchange(ShardLateFn fn, void* user, uint32_t listPresenceMask = 0, ShardDepthFn depthFn = nullptr, void* depthUser = nullptr);
 
 // Depth attachment of the last recorded base pass (read-back for tests; null before the first frame).
 nvrhi::TextureHandle GetLastDepthBuffer();

@@ -6,6 +6,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <exception>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -107,6 +108,8 @@ public:
             m_Cv.wait(lk, [&] { return job.done == n || !job.ready.empty(); });
         }
         m_Job = nullptr;                       // no task is running any more: nobody else refers to `job`
+        lk.unlock();
+        if (job.error) std::rethrow_exception(job.error);   // first exception a task threw, on whichever thread it ran
     }
 
 private:
@@ -115,6 +118,7 @@ private:
         Taskflow* flow = nullptr;
         std::vector<size_t> pending, ready;
         size_t done = 0;
+        std::exception_ptr error;
     };
 
     // Called with the lock held; returns with it held.
@@ -125,8 +129,10 @@ private:
             const size_t idx = job->ready.back();
             job->ready.pop_back();
             lk.unlock();
-            job->flow->m_Nodes[idx].fn();
+            std::exception_ptr thrown;
+            try { job->flow->m_Nodes[idx].fn(); } catch (...) { thrown = std::current_exception(); }
             lk.lock();
+            if (thrown && !job->error) job->error = thrown;
             ++job->done;
             size_t released = 0;
             for (size_t s : job->flow->m_Nodes[idx].successors)

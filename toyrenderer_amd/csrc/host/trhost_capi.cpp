@@ -220,6 +220,15 @@ int trhost_instance_buffer(void** buffer)
     return guarded([&] { *buffer = g_Scene->m_InstanceConstsBuffer ? (void*)g_Scene->m_InstanceConstsBuffer->native() : nullptr; });
 }
 
+int trhost_scene_list_sizes(uint32_t* num_opaque, uint32_t* num_alpha_mask)
+{
+    return guarded([&] {
+        check(num_opaque && num_alpha_mask);
+        *num_opaque = (uint32_t)g_Scene->m_OpaquePrimitiveIDs.size();
+        *num_alpha_mask = (uint32_t)g_Scene->m_AlphaMaskPrimitiveIDs.size();
+    });
+}
+
 int trhost_set_shard_late_exchange(trhost_shard_late_fn fn, void* user)
 {
     return guarded([&] { SetShardLateExchange(fn, user); });

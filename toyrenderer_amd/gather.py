@@ -184,6 +184,7 @@ class RcclComm:
             L.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
             L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
             L.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+            L.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
             L.ncclCommDestroy.argtypes = [C.c_void_p]
             L.ncclGetErrorString.restype = C.c_char_p
             L.ncclGetErrorString.argtypes = [C.c_int]
@@ -238,7 +239,9 @@ class NativeShardExchange:
 
     def __init__(self, renderer, dist, world: int, rank: int, slot_groups: int, pass_slots=(0, 1),
                  group_capacity: int | None = None, list_capacity: int | None = None, overlap: bool = True,
-                 stage_through_host: bool = False, loopback: bool = False):
+                 stage_through_host: bool = False, loopback: bool = False, raster_depth: bool = False):
+        """raster_depth: the frames rasterise their own depth (trhost_set_raster_depth): adds the cross-rank MAX of the
+        depth buffer before every HZB build (one more communicator / process group)."""
         import ctypes as C
 
         import torch
@@ -254,7 +257,17 @@ class NativeShardExchange:
         d.world, d.rank, d.slot_groups, d.group_capacity = self.world, self.rank, int(slot_groups), self.group_capacity
         d.list_capacity, d.overlap = self.list_capacity, int(bool(overlap))
         d.pass_slot_mask = sum(1 << s for s in self.pass_slots)
+        # which id lists exist on SOME rank: every rank posts the in-frame late-count collective of exactly those buckets
+        n_op, n_am = C.c_uint32(), C.c_uint32()
+        host._check(L.trhost_scene_list_sizes(C.byref(n_op), C.byref(n_am)))
+        present = [int(n_op.value > 0), int(n_am.value > 0)]
+        if not loopback and dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+            t = torch.tensor(present, dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            present = [int(v) for v in t.cpu().tolist()]
+        d.list_presence_mask = present[0] | (present[1] << 1)
         self.comms = []
+        self.collective = "loopback" if loopback else "host-staged" if stage_through_host else None
         if loopback:
             # diagnostic (bench.py --emulate-ranks with TR_EMULATE_LOOPBACK=1): ONE process plays rank `rank` of `world`; a
             # collective copies this rank's contribution into every slot on the device, so the unpack sees `world` shards
@@ -293,31 +306,70 @@ class NativeShardExchange:
                 self._keep.append(cb)
                 return C.cast(cb, C.c_void_p).value
             d.slots_allgather, d.late_allgather = staged(groups[0]), staged(groups[1])
+            if raster_depth:
+                dgroup = dist.new_group()
+
+                def depth_fn(_user, words, count, stream):
+                    try:
+                        torch.cuda.ExternalStream(int(stream or 0)).synchronize()
+                        dev = torch.as_tensor(_DevWords(int(words), int(count)), device="cuda")
+                        h = dev.cpu()                       # non-negative floats order like their int32 bit patterns
+                        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=dgroup)
+                        dev.copy_(h)
+                        torch.cuda.current_stream().synchronize()
+                        return 0
+                    except Exception as e:
+                        import sys
+                        print(f"[rank {rank}] staged depth all-reduce failed: {e}", file=sys.stderr, flush=True)
+                        return 1
+                dcb = host.DEPTH_ALLREDUCE_FN(depth_fn)
+                self._keep.append(dcb)
+                d.depth_allreduce_max = C.cast(dcb, C.c_void_p).value
         else:
             # Direct RCCL communicators; if any rank cannot create them (librccl not where torch keeps it, bootstrap
             # refused, ...) EVERY rank falls back to the process group's own all-gather on device tensors -- slower
             # (torch's stream hand-over per call) but the same data path, and said so on stderr.
             import os
             import sys
-            ok = 1
+
+            def agree(ok: int) -> bool:
+                flag = torch.tensor([int(ok)], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                return bool(int(flag.item()))
+
+            # Step 1: every rank checks its environment and the library LOCALLY (no communication), then all ranks agree.
+            # Only then does anyone touch a communicator, so a rank that cannot use RCCL directly never leaves the others
+            # waiting inside a broadcast or ncclCommInitRank.
+            ok, why = 1, ""
             try:
                 if os.environ.get("TR_NO_DIRECT_RCCL"):
                     raise RuntimeError("TR_NO_DIRECT_RCCL is set")
                 R = RcclComm.lib(torch)
                 fn_addr = C.cast(L.trhost_rccl_allgather, C.c_void_p).value
-                for _ in range(2):
-                    comm = RcclComm(dist, torch, self.world, self.rank)
-                    user = (C.c_void_p * 2)(C.cast(R.ncclAllGather, C.c_void_p).value, comm.comm.value)
-                    self.comms.append(comm)
-                    self._keep.append(user)
             except Exception as e:
-                ok = 0
-                print(f"[rank {rank}] direct RCCL communicator unavailable ({e}); using torch.distributed all_gather", file=sys.stderr, flush=True)
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()):
+                ok, why = 0, str(e)
+            direct = agree(ok)
+            if not direct and (why or rank == 0):
+                print(f"[rank {rank}] direct RCCL communicator unavailable ({why or 'another rank cannot use it'}); using torch.distributed all_gather", file=sys.stderr, flush=True)
+            if direct:
+                # Step 2: all ranks construct both communicators (same order), then agree on the outcome once more.
+                try:
+                    for k in range(3 if raster_depth else 2):
+                        comm = RcclComm(dist, torch, self.world, self.rank)
+                        user = (C.c_void_p * 2)(C.cast(R.ncclAllReduce if k == 2 else R.ncclAllGather, C.c_void_p).value, comm.comm.value)
+                        self.comms.append(comm)
+                        self._keep.append(user)
+                except Exception as e:
+                    ok = 0
+                    print(f"[rank {rank}] ncclCommInitRank failed ({e}); using torch.distributed all_gather", file=sys.stderr, flush=True)
+                direct = agree(ok)
+            self.collective = "rccl-direct" if direct else "pg"
+            if direct:
                 d.slots_allgather, d.slots_user = fn_addr, C.cast(self._keep[0], C.c_void_p).value
                 d.late_allgather, d.late_user = fn_addr, C.cast(self._keep[1], C.c_void_p).value
+                if raster_depth:
+                    d.depth_allreduce_max = C.cast(L.trhost_rccl_allreduce_max_u32, C.c_void_p).value
+                    d.depth_user = C.cast(self._keep[2], C.c_void_p).value
             else:
                 for c in self.comms:
                     c.destroy()
@@ -343,6 +395,23 @@ class NativeShardExchange:
                     self._keep.append(cb)
                     return C.cast(cb, C.c_void_p).value
                 d.slots_allgather, d.late_allgather = through_torch(groups[0], hand_over[0]), through_torch(groups[1], hand_over[1])
+                if raster_depth:
+                    dgroup, dstream = dist.new_group(), torch.cuda.Stream()
+
+                    def depth_fn(_user, words, count, stream):
+                        try:
+                            ext = torch.cuda.ExternalStream(int(stream or 0))
+                            with torch.cuda.stream(dstream):
+                                dstream.wait_stream(ext)
+                                dist.all_reduce(torch.as_tensor(_DevWords(int(words), int(count)), device="cuda"), op=dist.ReduceOp.MAX, group=dgroup)
+                                ext.wait_stream(dstream)
+                            return 0
+                        except Exception as e:
+                            print(f"[rank {rank}] depth all-reduce through torch.distributed failed: {e}", file=sys.stderr, flush=True)
+                            return 1
+                    dcb = host.DEPTH_ALLREDUCE_FN(depth_fn)
+                    self._keep.append(dcb)
+                    d.depth_allreduce_max = C.cast(dcb, C.c_void_p).value
         host._check(L.trhost_exchange_create(C.byref(d)))
         self._L = L
 

@@ -22,7 +22,7 @@ HOST_SYMBOLS = [
     "trhost_heap_sim", "trhost_set_shard_late_exchange", "trhost_set_gpu_timers",
     "trhost_rccl_allgather", "trhost_exchange_create", "trhost_exchange_run", "trhost_exchange_wait", "trhost_exchange_outputs",
     "trhost_exchange_destroy", "trhost_load_geometry", "trhost_set_raster_depth", "trhost_download_depth",
-    "trhost_load_scene_cached",
+    "trhost_load_scene_cached", "trhost_scene_list_sizes", "trhost_rccl_allreduce_max_u32",
 ]
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)   # trhost_allgather_fn
@@ -31,9 +31,11 @@ ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint
 class ExchangeDesc(C.Structure):
     _fields_ = [("world", C.c_uint32), ("rank", C.c_uint32), ("slot_groups", C.c_uint32), ("group_capacity", C.c_uint32),
                 ("list_capacity", C.c_uint64), ("pass_slot_mask", C.c_uint32), ("overlap", C.c_int),
-                ("slots_allgather", C.c_void_p), ("slots_user", C.c_void_p), ("late_allgather", C.c_void_p), ("late_user", C.c_void_p)]
+                ("slots_allgather", C.c_void_p), ("slots_user", C.c_void_p), ("late_allgather", C.c_void_p), ("late_user", C.c_void_p),
+                ("list_presence_mask", C.c_uint32), ("depth_allreduce_max", C.c_void_p), ("depth_user", C.c_void_p)]
 
 
+DEPTH_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)   # trhost_exchange_desc.depth_allreduce_max
 SHARD_LATE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int)   # trhost_shard_late_fn
 
 
@@ -83,6 +85,7 @@ def load() -> C.CDLL:
     L.trhost_renderer_times.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.trhost_set_gpu_timers.argtypes = [C.c_int]
     L.trhost_exchange_create.argtypes = [C.POINTER(ExchangeDesc)]
+    L.trhost_scene_list_sizes.argtypes = [C.POINTER(u32), C.POINTER(u32)]
     L.trhost_exchange_outputs.argtypes = [u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.trhost_set_shard_late_exchange.argtypes = [SHARD_LATE_FN, vp]
     L.trhost_heap_sim.argtypes = [u64, vp, u32, vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
