@@ -20,4 +20,5 @@ r.set_camera(view); r.frame()
 r.wait_idle()
 L.trhip_debug_read_stamps(out, 1)
 print("batches", out[0], "with fixups", out[1], "deferred lookups", out[2], "overflows", out[3])
+print("wave-steps on the fast arithmetic path", out[4], "on the exact path", out[5], "(needs -DTR_COUNT_PATHS)")
 r.shutdown()

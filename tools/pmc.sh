@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for G in "$@"; do
   echo "group $i: $G" >> $OUT/progress.log
-  timeout -k 10 240 rocprofv3 --pmc $G --output-format csv -d $OUT/g$i -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile $BARGS > /dev/null 2> $OUT/g$i.log || { tail -5 $OUT/g$i.log; }
+  timeout -k 5 100 rocprofv3 --pmc $G --output-format csv -d $OUT/g$i -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile $BARGS > /dev/null 2> $OUT/g$i.log || { tail -5 $OUT/g$i.log; }
   i=$((i+1))
 done
 python3 - "$OUT" <<'PY'

@@ -406,6 +406,323 @@ __device__ __forceinline__ bool coneBackfacingP(uint32_t packed, F3 cv, float r,
     return dot3(cv, axis) >= fma_(q23.y, lens.y, r);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The square roots and divisions of ONE cull step (culling.hlsli:56-62,79 and the normalize of basepass.hlsl:103),
+// evaluated together.  The arithmetic convention wants every '/' and sqrt correctly rounded (IEEE); the compiler's
+// expansions of them (v_div_scale / v_div_fmas / v_div_fixup around a Newton iteration, a rescaling square root) spend
+// about half of their instructions on operands near the ends of the exponent range.  When EVERY lane of the wave has
+// all its operands in a comfortable middle range those instructions are no-ops by definition:
+//   * v_div_scale returns its input and clears VCC unless an operand is zero / denormal / tiny (exponent <= 23), the
+//     denominator's reciprocal or the quotient would be denormal, or the exponents are >= 96 apart (ISA manual);
+//     with VCC = 0 v_div_fmas is a plain fma, and v_div_fixup only replaces the result for zero / inf / NaN operands or
+//     an exponent difference beyond the format, otherwise it copies it;
+//   * the 8-operation square root of sqrt2() is exact on [2^-96, FLT_MAX].
+// So the FAST path below runs the same Newton iterations without the glue -- bit for bit the compiler's results -- and
+// shares the refined reciprocal of `len` between the three components of the normalisation (it depends on the
+// denominator only).  One wave-uniform branch sends a wave with any operand outside the range through the EXACT path,
+// which is the code the kernel ran before (sqrt2 / div2: the compiler's full sequences).  Without the VCC traffic of
+// v_div_scale / v_div_fmas the independent chains also interleave, which removes the wait states dependent packed-fp32
+// instructions need on gfx950 (one s_nop each).
+//
+// Range argument (SAFE): the four radicands in [2^-96, 2^60], |r| <= 2^30 (with c.x^2 + c.z^2 - r^2 <= 2^60 that bounds
+// |c.x|, |c.y|, |c.z| by 2^30.5; without the occlusion test length(c)^2 <= 2^60 does), every numerator and denominator
+// at least 2^-30 in magnitude, nearPlane in [2^-20, 2^20].  Then all numerators / denominators are below 2^63, exponent
+// differences stay under 96, no reciprocal or quotient is denormal and no numerator has an exponent <= 23.
+struct StepQuot
+{
+    v2f mn, mx;               // (minx, miny), (maxx, maxy)            culling.hlsli:57-62
+    F3 tn;                    // normalize(mul(coneAxis, adjugate))     basepass.hlsl:103
+    float depthSphere;        // nearPlane / (c.z - r)                  culling.hlsli:79
+    float lenC;               // length(c)                              culling.hlsli:86
+    float cutoff;             // cone cutoff byte / 255                 basepass.hlsl:105
+};
+
+__device__ __forceinline__ v2f rcpRefined2(v2f d)                       // Fma1 of the fdiv expansion: depends on d only
+{
+    const v2f r = { __builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y) };
+    const v2f e0 = fma2(-d, r, splat2(1.0f));
+    return fma2(e0, r, r);
+}
+__device__ __forceinline__ v2f quotient2(v2f n, v2f d, v2f r1)          // the rest of the expansion, unscaled operands
+{
+    const v2f q = n * r1;
+    const v2f e1 = fma2(-d, q, n);
+    const v2f q1 = fma2(e1, r1, q);
+    const v2f e2 = fma2(-d, q1, n);
+    return fma2(e2, r1, q1);                                            // v_div_fmas with VCC = 0
+}
+__device__ __forceinline__ float rcpRefined1(float d)
+{
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fma_(fma_(-d, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float quotient1(float n, float d, float r1)
+{
+    const float q = n * r1;
+    const float q1 = fma_(fma_(-d, q, n), r1, q);
+    return fma_(fma_(-d, q1, n), r1, q1);
+}
+__device__ __forceinline__ v2f sqrtSeq2(v2f x)                          // sqrt2()'s in-range sequence, unconditionally
+{
+    const v2f y = { __builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y) };
+    const v2f g0 = x * y, h0 = y * splat2(0.5f);
+    const v2f r0 = fma2(-h0, g0, splat2(0.5f));
+    const v2f g1 = fma2(g0, r0, g0), h1 = fma2(h0, r0, h0);
+    const v2f d1 = fma2(-g1, g1, x);
+    return fma2(d1, h1, g1);
+}
+__device__ __forceinline__ float sqrtSeq1(float x)
+{
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g0 = x * y, h0 = y * 0.5f;
+    const float r0 = fma_(-h0, g0, 0.5f);
+    const float g1 = fma_(g0, r0, g0), h1 = fma_(h0, r0, h0);
+    return fma_(fma_(-g1, g1, x), h1, g1);
+}
+__device__ __forceinline__ float minAbs3(float a, float b, float c) { return min_(min_(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c)); }
+
+// basepass.hlsl:92-99: cone bytes -> axis (xyz * 2 - 1) and cutoff; x / 255 exactly (see u8Unorm)
+__device__ __forceinline__ F3 coneAxisCutoff(uint32_t packed, float* cutoff)
+{
+    const float rc = 0x1.010102p-8f;         // RN(1/255)
+    const v2f x01 = { (float)(packed & 0xFFu), (float)((packed >> 8) & 0xFFu) };
+    const v2f x23 = { (float)((packed >> 16) & 0xFFu), (float)(packed >> 24) };
+    const v2f q01i = x01 * rc, q23i = x23 * rc;
+    const v2f q01 = fma2(fma2(-q01i, splat2(255.0f), x01), splat2(rc), q01i);      // (q0, q1)
+    const v2f q23 = fma2(fma2(-q23i, splat2(255.0f), x23), splat2(rc), q23i);      // (q2, cutoff)
+    const v2f a01 = fma2(q01, splat2(2.0f), splat2(-1.0f));
+    *cutoff = q23.y;
+    return { a01.x, a01.y, fma_(q23.x, 2.0f, -1.0f) };
+}
+
+#ifdef TR_COUNT_PATHS
+#define TR_PATH_COUNT(exact) do { if ((threadIdx.x & 63u) == 0) atomicAdd(&g_pathCount[(exact) ? 1 : 0], 1ull); } while (0)
+#else
+#define TR_PATH_COUNT(exact) do {} while (0)
+#endif
+
+template <bool OCC, bool CONE>
+__device__ __forceinline__ void stepQuotients(bool active, F3 c, float r, uint32_t packed, const M33P& adj, float nearPlane, bool nearInRange, StepQuot& o)
+{
+    // active: the lane tests a meshlet.  The others (past the end of a record, records past the end of the list) run along
+    // on whatever operands they hold, never reach an output and must not send the wave down the EXACT path.
+    // ---- everything before the square roots: exact by construction, shared by both paths --------------------------
+    const v2f cxy = { c.x, c.y };
+    const float dz = c.z - r;                                          // culling.hlsli:79 denominator
+    F3 t = { 1.0f, 1.0f, 1.0f };
+    float st = 1.0f, sc = 1.0f;
+    o.cutoff = 0.0f;
+    if (CONE) {
+        const F3 a = coneAxisCutoff(packed, &o.cutoff);
+        t = mulVecP(a, adj);                                           // basepass.hlsl:103 mul(axis, adjugate)
+        st = dot3(t, t);
+        sc = dot3(c, c);                                               // culling.hlsli:86 length(center)^2
+    }
+    v2f cr = { 1.0f, 1.0f }, vArg = { 1.0f, 1.0f };
+    float crz = 1.0f;
+    const v2f czz = splat2(c.z);
+    if (OCC) {
+        cr = cxy * r;                                                  // :53 cr.xy
+        crz = c.z * r;                                                 // :53 cr.z
+        const float czr2 = fma_(c.z, c.z, -(r * r));                   // :54
+        vArg = fma2(cxy, cxy, splat2(czr2));                           // :56, :60 radicands
+    }
+    // ---- optimistic: the fast square roots and what hangs on them ---------------------------------------------------
+    v2f vv = { 1.0f, 1.0f }, lens = { 1.0f, 1.0f };
+    if (OCC) vv = sqrtSeq2(vArg);                                      // :56, :60  vx, vy
+    if (CONE) lens = sqrtSeq2(v2f{ st, sc });                          // length(t), length(c)
+    v2f n1 = cxy, d1 = cxy, n2 = cxy, d2 = cxy;
+    if (OCC) {
+        n1 = fma2(vv, cxy, splat2(-crz)); d1 = fma2(vv, czz, cr);      // :57, :61
+        n2 = fma2(vv, cxy, splat2(crz));  d2 = fma2(vv, czz, -cr);     // :58, :62
+    }
+    // ---- is every operand of this lane in the comfortable range? ---------------------------------------------------
+    const uint32_t kLo = 0x0F800000u, kHi = 0x5D800000u;               // 2^-96, 2^60
+    uint32_t uMin = 0x3F800000u, uMax = 0x3F800000u;                   // radicands as bit patterns: negative / NaN read as huge
+    float mag = 1.0f;
+    bool rOk = true;
+    if (OCC) {
+        uMin = min(__float_as_uint(vArg.x), __float_as_uint(vArg.y));
+        uMax = max(max(__float_as_uint(vArg.x), __float_as_uint(vArg.y)), uMax);
+        mag = min_(min_(minAbs3(n1.x, n1.y, n2.x), minAbs3(n2.y, d1.x, d1.y)), minAbs3(d2.x, d2.y, dz));
+        rOk = __builtin_fabsf(r) <= 0x1p30f;                           // false for NaN
+    }
+    if (CONE) {
+        uMin = min(min(__float_as_uint(st), __float_as_uint(sc)), uMin);
+        uMax = max(max(__float_as_uint(st), __float_as_uint(sc)), uMax);
+        mag = min_(mag, minAbs3(t.x, t.y, t.z));
+    }
+    const bool safe = ((uMin >= kLo) & (uMax <= kHi) & (mag >= 0x1p-30f) & rOk & nearInRange) | !active;
+    if (__builtin_expect(__ballot(!safe) != 0ull, 0)) {
+        // ---- EXACT path (rare): the compiler's full square root / division sequences, as before ---------------------
+        TR_PATH_COUNT(true);
+        if (OCC) {
+            vv = sqrt2(vArg);
+            o.mn = div2(fma2(vv, cxy, splat2(-crz)), fma2(vv, czz, cr));
+            o.mx = div2(fma2(vv, cxy, splat2(crz)), fma2(vv, czz, -cr));
+        }
+        if (CONE) {
+            lens = sqrt2(v2f{ st, sc });
+            const v2f txy = div2(v2f{ t.x, t.y }, splat2(lens.x));      // normalize = v / length
+            const v2f tzq = div2(v2f{ t.z, nearPlane }, v2f{ lens.x, dz });
+            o.tn = { txy.x, txy.y, tzq.x };
+            o.depthSphere = tzq.y;
+            o.lenC = lens.y;
+        } else {
+            o.depthSphere = OCC ? div_(nearPlane, dz) : 0.0f;
+        }
+    } else {
+        // ---- FAST path: the same Newton iterations on unscaled operands, the independent chains issued side by side.
+        // (Stage by stage with scheduling barriers: left alone, the compiler emits one chain after the other and every
+        // dependent packed instruction then costs a wait state.)
+        TR_PATH_COUNT(false);
+#define TR_STAGE() __builtin_amdgcn_sched_barrier(0x0094)              /* SALU, VMEM and DS may cross; VALU may not */
+        if (OCC && CONE) {
+            const v2f d3 = { lens.x, dz }, dl = splat2(lens.x);
+            const v2f n3 = { t.x, t.y }, n4 = { t.z, nearPlane };
+            const v2f ra = { __builtin_amdgcn_rcpf(d1.x), __builtin_amdgcn_rcpf(d1.y) };
+            const v2f rb = { __builtin_amdgcn_rcpf(d2.x), __builtin_amdgcn_rcpf(d2.y) };
+            const v2f rc = { __builtin_amdgcn_rcpf(d3.x), __builtin_amdgcn_rcpf(d3.y) };
+            TR_STAGE();
+            const v2f ea = fma2(-d1, ra, splat2(1.0f)), eb = fma2(-d2, rb, splat2(1.0f)), ec = fma2(-d3, rc, splat2(1.0f));
+            TR_STAGE();
+            const v2f r1 = fma2(ea, ra, ra), r2 = fma2(eb, rb, rb), r3 = fma2(ec, rc, rc);
+            const v2f rl = splat2(r3.x);
+            TR_STAGE();
+            const v2f qa = n1 * r1, qb = n2 * r2, qc = n3 * rl, qd = n4 * r3;
+            TR_STAGE();
+            const v2f fa = fma2(-d1, qa, n1), fb = fma2(-d2, qb, n2), fc = fma2(-dl, qc, n3), fd = fma2(-d3, qd, n4);
+            TR_STAGE();
+            const v2f ga = fma2(fa, r1, qa), gb = fma2(fb, r2, qb), gc = fma2(fc, rl, qc), gd = fma2(fd, r3, qd);
+            TR_STAGE();
+            const v2f ha = fma2(-d1, ga, n1), hb = fma2(-d2, gb, n2), hc = fma2(-dl, gc, n3), hd = fma2(-d3, gd, n4);
+            TR_STAGE();
+            o.mn = fma2(ha, r1, ga); o.mx = fma2(hb, r2, gb);
+            const v2f txy = fma2(hc, rl, gc), tzq = fma2(hd, r3, gd);
+            TR_STAGE();
+            o.tn = { txy.x, txy.y, tzq.x };
+            o.depthSphere = tzq.y;
+            o.lenC = lens.y;
+        } else if (OCC) {
+            const v2f ra = { __builtin_amdgcn_rcpf(d1.x), __builtin_amdgcn_rcpf(d1.y) };
+            const v2f rb = { __builtin_amdgcn_rcpf(d2.x), __builtin_amdgcn_rcpf(d2.y) };
+            const float rc = __builtin_amdgcn_rcpf(dz);
+            TR_STAGE();
+            const v2f ea = fma2(-d1, ra, splat2(1.0f)), eb = fma2(-d2, rb, splat2(1.0f));
+            const float ec = fma_(-dz, rc, 1.0f);
+            TR_STAGE();
+            const v2f r1 = fma2(ea, ra, ra), r2 = fma2(eb, rb, rb);
+            const float r3 = fma_(ec, rc, rc);
+            TR_STAGE();
+            const v2f qa = n1 * r1, qb = n2 * r2;
+            const float qc = nearPlane * r3;
+            TR_STAGE();
+            const v2f fa = fma2(-d1, qa, n1), fb = fma2(-d2, qb, n2);
+            const float fc = fma_(-dz, qc, nearPlane);
+            TR_STAGE();
+            const v2f ga = fma2(fa, r1, qa), gb = fma2(fb, r2, qb);
+            const float gc = fma_(fc, r3, qc);
+            TR_STAGE();
+            const v2f ha = fma2(-d1, ga, n1), hb = fma2(-d2, gb, n2);
+            const float hc = fma_(-dz, gc, nearPlane);
+            TR_STAGE();
+            o.mn = fma2(ha, r1, ga); o.mx = fma2(hb, r2, gb);
+            o.depthSphere = fma_(hc, r3, gc);
+        } else if (CONE) {
+            const float r3 = rcpRefined1(lens.x);
+            const v2f txy = quotient2(v2f{ t.x, t.y }, splat2(lens.x), splat2(r3));
+            o.tn = { txy.x, txy.y, quotient1(t.z, lens.x, r3) };
+            o.depthSphere = 0.0f;
+            o.lenC = lens.y;
+        } else {
+            o.depthSphere = 0.0f;
+        }
+#undef TR_STAGE
+    }
+}
+
+// culling.hlsli:64-78 from the four quotients on: clamp, ClipXYToUV, mip level, footprint origin.
+struct OccUv { v2f uv; int mip; };
+__device__ __forceinline__ v2f occClampUv(v2f m, v2f P)
+{
+    const v2f s = m * P;                                               // :64-67
+    const v2f cl = { clamp_(s.x, -1.0f, 1.0f), clamp_(s.y, -1.0f, 1.0f) };
+    return fma2(cl, v2f{ 0.5f, -0.5f }, splat2(0.5f));                 // :70-71 ClipXYToUV
+}
+
+// Footprint-min table path.  mipTab[e], e = floor(log2(max(w, h, 1))) + 1 clamped to `mips` (what v_frexp_exp returns):
+// { first table entry of mip e-1 + its row stride + 1, row stride (= mip width + 1), (float)width, (float)height }.
+__device__ __forceinline__ OccQuad occTailQuad(const StepQuot& q, F3 c, float r, float nearPlane, float P00, float P11, const Hzb& h,
+                                               const uint4* mipTab, uint32_t quadTotal)
+{
+    OccQuad o;
+    o.accept = (c.z - nearPlane) < r;                                  // :48-49
+    const v2f P = { P00, P11 };
+    const v2f lo = occClampUv(q.mn, P), hi = occClampUv(q.mx, P);      // (ax, ay), (az, aw)
+    const v2f wh = (hi - lo) * v2f{ (float)h.width, (float)h.height }; // :73-74
+    // :75 floor(log2(max(w, h))), clamped by SampleLevel to [0, mips-1]; anything below 1 (and NaN) -> mip 0 (Q6)
+    const float m = max_(max_(wh.x, wh.y), 1.0f);
+    int e = __builtin_amdgcn_frexp_expf(m);                            // exponent + 1 of a finite m >= 1
+    e = e < (int)h.mips ? e : (int)h.mips;
+    e = e > 1 ? e : 1;
+    const uint4 tab = mipTab[e];
+    const v2f uv = (lo + hi) * splat2(0.5f);                           // :78
+    const v2f f = fma2(uv, v2f{ __uint_as_float(tab.z), __uint_as_float(tab.w) }, splat2(-0.5f));
+    const float flx = __builtin_floorf(f.x), fly = __builtin_floorf(f.y);
+    const int x0 = (int)flx, y0 = (int)fly;                            // in [-1, mw-1] x [-1, mh-1]
+    const uint32_t iq = (uint32_t)(__mul24(y0, (int)tab.y) + x0) + tab.x;   // == offset + (y0+1) * (mw+1) + (x0+1)
+    o.iq = min(iq, quadTotal - 1u);
+    // A zero weight drops the second column (row) from the footprint; that only changes the set of texels when the
+    // second column (row) is a different texel after edge clamping, i.e. 0 <= x0 and x0 + 1 <= mw - 1.  Rare: only a
+    // wave that has an exactly integral coordinate somewhere looks at the rest of the condition.
+    const bool zx = !(f.x > flx), zy = !(f.y > fly);
+    o.slow = false;
+    if (__builtin_expect(__ballot(zx | zy) != 0ull, 0)) {
+        const int mw = (int)tab.y - 1, mh = (int)__uint_as_float(tab.w);
+        o.slow = (zx & (x0 >= 0) & (x0 + 1 < mw)) | (zy & (y0 >= 0) & (y0 + 1 < mh));
+    }
+    o.depthSphere = q.depthSphere;
+    return o;
+}
+
+// Texel path: the same, ending in the two texel-pair indices (see occlusionPrepare).
+__device__ __forceinline__ OccSample occTailTexel(const StepQuot& q, F3 c, float r, float nearPlane, float P00, float P11, const Hzb& h, const uint32_t* mipOff)
+{
+    OccSample o;
+    o.accept = (c.z - nearPlane) < r;                                  // :48-49
+    const v2f P = { P00, P11 };
+    const v2f lo = occClampUv(q.mn, P), hi = occClampUv(q.mx, P);
+    const v2f wh = (hi - lo) * v2f{ (float)h.width, (float)h.height };
+    const int mip = hzbLevel(wh.x, wh.y, h.mips);                      // :75
+    const v2f uv = (lo + hi) * splat2(0.5f);                           // :78
+    const uint32_t mw = (h.width >> mip) ? (h.width >> mip) : 1u;
+    const uint32_t mh = (h.height >> mip) ? (h.height >> mip) : 1u;
+    const v2f f = fma2(uv, v2f{ (float)mw, (float)mh }, splat2(-0.5f));
+    const float flx = __builtin_floorf(f.x), fly = __builtin_floorf(f.y);
+    int x0 = (int)flx, y0 = (int)fly;
+    const bool wx1 = (f.x - flx) > 0.0f, wy1 = (f.y - fly) > 0.0f;
+    const int xm = (int)mw - 1, ym = (int)mh - 1;
+    int x1 = min(max(x0 + 1, 0), xm), y1 = min(max(y0 + 1, 0), ym);
+    x0 = min(max(x0, 0), xm);
+    y0 = min(max(y0, 0), ym);
+    x1 = wx1 ? x1 : x0;
+    y1 = wy1 ? y1 : y0;
+    const uint32_t base = mipOff[mip];
+    o.i0 = base + (uint32_t)y0 * mw + (uint32_t)x0;
+    o.i1 = base + (uint32_t)y1 * mw + (uint32_t)x0;
+    o.pair = x1 != x0;                                                 // then x1 == x0 + 1
+    o.depthSphere = q.depthSphere;
+    return o;
+}
+
+// basepass.hlsl:104-107 + ConeCull (culling.hlsli:84-87) from the normalised axis on; true = back-facing
+__device__ __forceinline__ bool coneTail(const StepQuot& q, F3 cv, float r, const M33P& viewRot)
+{
+    F3 axis = mulVecP(q.tn, viewRot);
+    axis.z = -axis.z;
+    return dot3(cv, axis) >= fma_(q.cutoff, q.lenC, r);
+}
+
 __device__ __forceinline__ M43 loadM43(const interop::Matrix& m)
 {
     return { { m.m[0][0], m.m[0][1], m.m[0][2] }, { m.m[1][0], m.m[1][1], m.m[1][2] },

@@ -34,6 +34,10 @@
 #include <string>
 #include <type_traits>
 
+#if defined(TR_STAMPS) || defined(TR_COUNT_SLOW) || defined(TR_COUNT_PATHS)   // diagnostic builds only (never shipped, never timed)
+__device__ unsigned long long g_stampSums[8];
+#define g_pathCount (g_stampSums + 4)          // [4] steps on the fast arithmetic path, [5] on the exact path (TR_COUNT_PATHS)
+#endif
 #include "cull_math.hip.h"
 #include "instance_cache.hip.h"
 #include "trhip_internal.h"
@@ -49,16 +53,18 @@ constexpr uint32_t kBatch = 64;                  // records per wave batch
 constexpr uint32_t kSteps = kBatch / 2;          // two records per wave step
 constexpr uint32_t kSlowCap = 64;                // per wave and batch: lookups deferred to the texel path (see OccQuad::slow)
 
-struct RecordInfo                                 // per-record invariants parked in LDS (96 B)
+struct RecordInfo                                 // per-record invariants parked in LDS (112 B, read as 128-bit words)
 {
     float wxy[8];                                 // world matrix rows 0..3: (x, y) pairs (8-byte aligned: read as packed operands)
     float wz[4];                                  //                         z column
     float adjxy[6];                               // MakeAdjugateMatrix rows 0..2: (x, y) pairs
     float adjz[3];                                //                               z column
     float maxScale;
-    uint32_t meshletBase;                         // m_MeshletDataBufferIdx + m_MeshletGroupOffset
+    const MeshletData* first;                     // &meshlets[m_MeshletDataBufferIdx + m_MeshletGroupOffset] (the buffer's start when count == 0)
     uint32_t count;                               // lanes with meshletIdx < m_NumMeshlets (0..32)
+    uint32_t pad[3];
 };
+static_assert(sizeof(RecordInfo) == 112 && offsetof(RecordInfo, first) == 88, "RecordInfo layout");
 
 __device__ __forceinline__ cm::M43P worldOf(const RecordInfo& ri)
 {
@@ -102,52 +108,43 @@ __device__ __forceinline__ uint32_t groupCount(const MeshletCullArgs& a)
     return G < a.recordCapacity ? G : a.recordCapacity;
 }
 
-// A record's MeshletData (<= 32 x 32 B = 1 KB) is fetched as whole lines: per half-wave, lane `sub`
-// loads 16-byte chunk `sub` (instruction A: meshlets 0-15) and chunk `32 + sub` (instruction B:
-// meshlets 16-31) -- 512 contiguous bytes per half-wave and instruction, i.e. 16 L1 accesses per wave
-// instruction instead of 64 for a 32-byte-stride gather.  Chunk parity = which half of the struct:
-// an even lane holds two bounding spheres, its odd neighbour the matching cone words.  The pairs are
-// completed with one DPP lane swap: the even lane then tests meshlet sub/2, the odd lane meshlet
-// 16 + sub/2 (the ballot is un-permuted before it is stored).
-// Every lane always loads (lanes past the record's end re-read chunk 0): with no exec-masked or
-// conditional loads in the loop the compiler can count outstanding loads exactly and emits partial
-// s_waitcnt vmcnt(N) instead of vmcnt(0).
 typedef float v4f __attribute__((ext_vector_type(4)));
-struct MeshletRegs { v4f a, b; };                // kept as two 128-bit register tuples from the load to the first use
-
-__device__ __forceinline__ MeshletRegs loadMeshletChunks(const MeshletData* meshlets, uint32_t base, uint32_t count, uint32_t sub)
+// The two records of a step (2 x 1 KB of MeshletData) go from memory STRAIGHT INTO LDS (global_load_lds_dwordx4: no
+// VGPRs in between) as whole cache lines: per half-wave, lane `sub` moves 16-byte chunk `sub` (instruction A: meshlets
+// 0-15) and chunk 32 + sub (instruction B: meshlets 16-31) of its record, so every 128-byte line is requested from the L2
+// exactly once, by one instruction.  That matters more than anything else in this kernel: its pace is set by the L1
+// misses a CU can keep in flight (TCP_PENDING_STALL 60-70 % of the cycles, TA busy 85 %: profiles/r2), not by HBM or by
+// VALU issue.  Each lane then reads ITS OWN meshlet's sphere (ds_read_b128) and cone word (ds_read_b32) out of the staged
+// kilobyte.  (Round 1 kept the chunks in VGPRs and completed the (sphere, cone) pairs with DPP swaps, selects and a
+// shuffled ballot: 14 vector + 40 scalar instructions per step.  Loading 16 + 4 bytes per lane directly -- tried first
+// this round -- asks the L2 for every line twice: 5 % SLOWER than round 1 with 25 % fewer instructions executed.)
+//
+// The compiler's wait-count pass cannot tell LDS-DMA targets apart (any LDS read after a global_load_lds builtin waits
+// for vmcnt(0), which would serialise the prefetch), so the ring is driven by hand: the loads, the table lookup that
+// shares their counter and every wait on vmcnt in the loop are inline assembly, and the loop contains no other vector
+// memory instruction.  Loads return in order, so a wait "until at most N are outstanding" is exact.
+//
+// LDS layout of a ring slot (2 KB per wave): [0,512) record A chunks 0-31, [512,1024) record B chunks 0-31,
+// [1024,1536) record A chunks 32-63, [1536,2048) record B chunks 32-63.
+__device__ __forceinline__ void issueMeshletLoads(char* slotLds /* wave-uniform */, const MeshletData* first, uint32_t count, uint32_t sub)
 {
-    const v4f* p = reinterpret_cast<const v4f*>(meshlets + (count ? base : 0u));
+    // Every lane always loads (chunks past the record's end re-read chunk 0): the number of loads in flight never
+    // depends on the data.
     const uint32_t nChunks = count * 2u;
     const uint32_t ja = sub < nChunks ? sub : 0u, jb = 32u + sub < nChunks ? 32u + sub : 0u;
-    MeshletRegs m;
-    // basepass.hlsl:65.  Non-temporal: the 1.8 GB meshlet stream is read once and must not evict the HZB
-    // footprint table and the per-record data from the 4 MB L2s (measured -3 % on the kernel).
-    m.a = __builtin_nontemporal_load(p + ja);
-    m.b = __builtin_nontemporal_load(p + jb);
-    return m;
+    const char* p = reinterpret_cast<const char*>(first);
+    const char* pa = p + 16u * ja;                                                   // basepass.hlsl:65
+    const char* pb = p + 16u * jb;
+    const uint32_t ldsOff = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)slotLds;
+    // nt: the 1.8 GB stream is read once and must not evict the HZB table and the per-record data from the L2s
+    asm volatile("s_mov_b32 m0, %2\n\t"
+                 "global_load_lds_dwordx4 %0, off nt\n\t"
+                 "s_add_u32 m0, %2, 0x400\n\t"
+                 "global_load_lds_dwordx4 %1, off nt"
+                 :: "v"(pa), "v"(pb), "s"(ldsOff) : "memory", "m0", "scc");
 }
+#define TR_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-__device__ __forceinline__ float swapWithNeighbour(float v)   // quad_perm [1,0,3,2]
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-}
-
-// bits 0,2,4,... of x -> bits 0..31
-__device__ __forceinline__ uint32_t compressEvenBits(unsigned long long x)
-{
-    x &= 0x5555555555555555ull;
-    x = (x | (x >> 1)) & 0x3333333333333333ull;
-    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
-    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
-    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
-    x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
-    return (uint32_t)x;
-}
-
-#if defined(TR_STAMPS) || defined(TR_COUNT_SLOW)   // diagnostic builds only (never shipped, never timed)
-__device__ unsigned long long g_stampSums[8];
-#endif
 #ifdef TR_STAMPS
 #define TR_STAMP(i) do { unsigned long long _t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); stampSum[i] += _t - stampLast; stampLast = _t; } while (0)
 #else
@@ -165,12 +162,14 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
     unsigned long long stampLast = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-    __shared__ RecordInfo s_recAll[kWaves][kBatch];
+    __shared__ RecordInfo s_recAll[kWaves][kBatch + 4];           // + 4: the prefetch of the last two steps reads past the batch (count 0)
     __shared__ uint32_t s_gIdxAll[kWaves][kBatch];
-    __shared__ uint32_t s_quadOff[16];
+    __shared__ uint32_t s_quadOff[16];                 // texel path: mip offsets
+    __shared__ uint4 s_mipTab[17];                     // table path: per-mip constants indexed by exponent + 1 (cm::occTailQuad)
     __shared__ uint32_t s_slowAll[kWaves][kSlowCap];
     __shared__ uint32_t s_slowCount[kWaves];
     __shared__ uint32_t s_maskAll[kWaves][kBatch];
+    __shared__ __attribute__((aligned(16))) char s_ring[kWaves][2][2048];   // per wave: two ring slots of staged MeshletData
 
     const uint32_t G = groupCount(a);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -181,47 +180,61 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
     RecordInfo* s_rec = s_recAll[wave];
     uint32_t* s_gIdx = s_gIdxAll[wave];
 
-    if (tid < 16) s_quadOff[tid] = TABLE ? a.quad.offset[tid] : a.hzb.mipOffset[tid];   // table offsets / mip offsets (texel path)
+    if (tid < 16) s_quadOff[tid] = a.hzb.mipOffset[tid];
+    if (TABLE && tid >= 1 && tid <= 16) {
+        const uint32_t mip = tid - 1u < a.hzb.mips ? tid - 1u : 0u;
+        const uint32_t mw = (a.hzb.width >> mip) ? (a.hzb.width >> mip) : 1u, mh = (a.hzb.height >> mip) ? (a.hzb.height >> mip) : 1u;
+        s_mipTab[tid] = make_uint4(a.quad.offset[mip] + mw + 2u, mw + 1u, __float_as_uint((float)mw), __float_as_uint((float)mh));
+    }
+    // the fast arithmetic path wants nearPlane in [2^-20, 2^20] (cm::stepQuotients)
+    const bool nearInRange = a.k.m_NearPlane >= 0x1p-20f && a.k.m_NearPlane <= 0x1p20f;
     if (tid < kWaves) s_slowCount[tid] = 0;
+    if (lane < 4) { s_recAll[wave][kBatch + lane].first = a.meshlets; s_recAll[wave][kBatch + lane].count = 0; }
     uint32_t* s_slow = s_slowAll[wave];
     uint32_t* s_mask = s_maskAll[wave];
     __syncthreads();                                                                 // the only workgroup barrier
 
-    // Work decomposition: the record list is cut into SUPER-BATCHES of 64 * numWaves records; inside
-    // one, wave w runs records {2*numWaves*s + 2*w + half} at step s.  All waves of the chip thus
-    // walk a moving window of ~2*numWaves consecutive records (instead of numWaves windows 64 records
-    // apart), which keeps the HZB texels touched at any one time close together (L2/L1 locality).
-    // Records are processed in screen-tile order when the instance pass published one for exactly
-    // this record count (any permutation of [0,G) is a valid processing order: masks are stored by
-    // record index); otherwise in record order.
+    // Work decomposition.  Records are processed in screen-tile order when the instance pass published one for exactly
+    // this record count (any permutation of [0,G) is a valid processing order: masks are stored by record index);
+    // otherwise in record order.  The order is cut into WINDOWS of 64 * kWaves = 256 consecutive records; workgroup b takes
+    // windows b, b + gridDim, ...; inside a window, wave w runs records {2 * kWaves * s + 2 * w + half} at step s.  The
+    // waves of a workgroup thus stay inside 256 consecutive records (in tile order: a few dozen instances of one screen
+    // region) for a whole batch, and the HZB lookups of a CU keep hitting the same few table rows in its L1.
+    // (Round 1 walked ONE window of 2 * numWaves records with all waves of the chip -- good for the L2s, but every CU then
+    // touched a different screen region at every step and 3 of 4 lookups missed its L1: -DTR_TEAM_ALL, 3 % slower.)
     const bool usePerm = a.permHeader != nullptr && a.permHeader[0] == 1u && a.permHeader[1] == G;
-    const uint32_t numWaves = gridDim.x * kWaves;
-    const uint32_t waveId = blockIdx.x * kWaves + wave;
-    const uint32_t superSize = numWaves * kBatch;
+#ifndef TR_TEAM_ALL
+    const uint32_t teamWaves = kWaves, waveInTeam = wave, team = blockIdx.x, teams = gridDim.x;
+#else
+    const uint32_t teamWaves = gridDim.x * kWaves, waveInTeam = blockIdx.x * kWaves + wave, team = 0u, teams = 1u;
+#endif
+    const uint32_t superSize = teamWaves * kBatch;
     const uint32_t numSuper = (G + superSize - 1) / superSize;
     // The batch entry of lane l = the record of step l/2, half l&1, as {record index, instance, lod, group offset}
     // (0xFFFFFFFF = none): from the permuted copy the instance pass wrote, or from the record buffer itself.
-    auto loadEntry = [&](uint32_t sbBase_) -> uint4 {
-        const uint32_t e = sbBase_ + (lane >> 1) * 2 * numWaves + 2 * waveId + (lane & 1);
-        if (e >= G) return make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+    auto loadEntry = [&](uint32_t sb_) -> uint4 {
+        const uint64_t e64 = (uint64_t)sb_ * superSize + (lane >> 1) * 2 * teamWaves + 2 * waveInTeam + (lane & 1);
+        if (sb_ >= numSuper || e64 >= G) return make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+        const uint32_t e = (uint32_t)e64;
         if (usePerm) return a.perm[e];
         const MeshletAmplificationData rec = a.records[e];
         return make_uint4(e, rec.m_InstanceConstIdx, rec.m_MeshLOD, rec.m_MeshletGroupOffset);
     };
-    uint4 entry = loadEntry(0u);
-    for (uint32_t sb = 0; sb < numSuper; ++sb) {
+    uint4 entry = loadEntry(team);
+    for (uint32_t sb = team; sb < numSuper; sb += teams) {
         const uint32_t sbBase = sb * superSize;
-        if (sbBase + 2 * waveId >= G) break;                                         // nothing left for this wave
-        // steps of this super-batch that still hold records for this wave (wave-uniform), rounded up to even
-        const uint32_t remaining = G - sbBase - 2 * waveId;
-        uint32_t nSteps = (remaining + 2 * numWaves - 1) / (2 * numWaves);
+        if (sbBase + 2 * waveInTeam >= G) break;                                     // nothing left for this wave
+        // steps of this window that still hold records for this wave (wave-uniform), rounded up to even
+        const uint32_t remaining = G - sbBase - 2 * waveInTeam;
+        uint32_t nSteps = (remaining + 2 * teamWaves - 1) / (2 * teamWaves);
         nSteps = nSteps < kSteps ? (nSteps + 1u) & ~1u : kSteps;
         TR_STAMP(0);   // between batches
         // ---- prologue: lane l resolves its record (basepass.hlsl:52-58) through the instance cull cache: ONE
         //      level of dependent loads here -- the entry itself was fetched while the previous batch ran ------
         {
             RecordInfo ri;
-            ri.count = 0; ri.meshletBase = 0; ri.maxScale = 0.f;
+            ri.count = 0; ri.first = a.meshlets; ri.maxScale = 0.f;
+            ri.pad[0] = ri.pad[1] = ri.pad[2] = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) ri.wxy[i] = 0.f;
 #pragma unroll
@@ -231,7 +244,7 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
 #pragma unroll
             for (int i = 0; i < 3; ++i) ri.adjz[i] = 0.f;
             const uint4 cur = entry;
-            entry = loadEntry(sbBase + superSize);                                   // next batch's entry: in flight during this batch
+            entry = loadEntry(sb + teams);                                           // next batch's entry: in flight during this batch
             const uint32_t g = cur.x < G ? cur.x : 0xFFFFFFFFu;
             s_gIdx[lane] = g;
             if (g < G) {
@@ -258,7 +271,7 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
                 const uint64_t base = (uint64_t)lodMeshletBase + off;
                 if (base + cnt > a.numMeshlets) cnt = 0;                             // never read outside the meshlet buffer
                 ri.count = cnt;
-                ri.meshletBase = (uint32_t)base;
+                if (cnt) ri.first = a.meshlets + base;
             }
             s_rec[lane] = ri;
         }
@@ -269,98 +282,91 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         TR_STAMP(1);   // prologue
-        // ---- main loop: two records per step, meshlet data two steps ahead ----------------------
-        // Slot A strictly before slot B, as in the loop: the wait-count pass merges the loop's entry state with its
-        // back-edge state, and only when both look alike does the wait at the loop top stay partial (vmcnt(2)).
-        MeshletRegs slotA = loadMeshletChunks(a.meshlets, s_rec[half].meshletBase, s_rec[half].count, sub);
-        __builtin_amdgcn_sched_barrier(0);
-        MeshletRegs slotB = loadMeshletChunks(a.meshlets, s_rec[2 + half].meshletBase, s_rec[2 + half].count, sub);
-        __builtin_amdgcn_sched_barrier(0);
-        const bool odd = (sub & 1u) != 0;
-        const uint32_t myMeshlet = odd ? 16u + (sub >> 1) : (sub >> 1);             // index inside the group
+        // ---- main loop: two records per step, their MeshletData staged in LDS two steps ahead ---------------------
+        // Loads outstanding at the top of a step: {this slot's 2, the other slot's 2}; after the step's table lookup and
+        // its prefetch: {other slot's 2, lookup, this slot's 2}.  Both waits are therefore vmcnt(2).
+        char* const ringA = s_ring[__builtin_amdgcn_readfirstlane((int)wave)][0];
+        char* const ringB = ringA + 2048;
+        const uint32_t ringOff = (sub < 16u ? 0u : 512u) + half * 512u + sub * 32u;  // this lane's meshlet inside a ring slot
+        issueMeshletLoads(ringA, s_rec[half].first, s_rec[half].count, sub);
+        issueMeshletLoads(ringB, s_rec[2 + half].first, s_rec[2 + half].count, sub);
 
-        auto step = [&](MeshletRegs& slot, uint32_t s) {
+        auto step = [&](char* slot, uint32_t s) {
             TR_STAMP(7);   // loop overhead / previous tail
             const uint32_t r = 2 * s + half;                                         // record within the batch
             const RecordInfo& ri = s_rec[r];
-            // The ring slot is consumed HERE as two whole 128-bit tuples.  (Without this the compiler carries the eight
-            // dwords across the loop back-edge one by one, copies some of them at the end of the iteration and has to
-            // drain the prefetch that was issued a moment before: s_waitcnt vmcnt(0) at every loop top.)
-            asm volatile("" : "+v"(slot.a), "+v"(slot.b));
-            // complete the (sphere, cone) pair with the neighbour lane
-            const float r0 = swapWithNeighbour(odd ? slot.a.x : slot.b.x);
-            const float r1 = swapWithNeighbour(slot.b.y), r2 = swapWithNeighbour(slot.b.z), r3 = swapWithNeighbour(slot.b.w);
-            const float4 sphere = odd ? make_float4(r0, r1, r2, r3) : make_float4(slot.a.x, slot.a.y, slot.a.z, slot.a.w);
-            const uint32_t cone = __float_as_uint(odd ? slot.b.x : r0);
-            bool vis = myMeshlet < ri.count;
+            TR_WAIT_VMCNT(2);                                                        // this slot has landed
+            const v4f sph = *reinterpret_cast<const v4f*>(slot + ringOff);
+            const uint32_t cone = *reinterpret_cast<const uint32_t*>(slot + ringOff + 16u);
+            const float4 sphere = make_float4(sph.x, sph.y, sph.z, sph.w);
+            const bool active = sub < ri.count;                                                    // :62-63
+            bool vis = active;
             const cm::M43P W = worldOf(ri);
             const cm::F3 cw = cm::mulPointP({ sphere.x, sphere.y, sphere.z }, W);                  // :67
             const cm::F3 cv = cm::toViewP(cw, VP);                                                 // :68-69
             const float rad = sphere.w * ri.maxScale;                                              // :71
             if (FRUSTUM)
                 vis &= cm::frustumVisible(cv, rad, a.k.m_Frustum.x, a.k.m_Frustum.y, a.k.m_Frustum.z, a.k.m_Frustum.w); // :73
-            TR_STAMP(2);   // wait for data + exchange + transform + frustum
+            TR_STAMP(2);   // wait for data + transform + frustum
+            // every square root and division of the step (:56-62, :79, normalize :103): fast when the whole wave can
+            cm::StepQuot q;
+            if (OCCLUSION || CONE)
+                cm::stepQuotients<OCCLUSION, CONE>(active, cv, rad, cone, adjugateOf(ri), a.k.m_NearPlane, nearInRange, q);
             cm::OccQuad oq;
             cm::OccSample os;
             uint32_t footprintBits = 0, row0 = 0, row1 = 0;
             if (OCCLUSION && TABLE) {                                                              // :75-88 (Q4)
-                oq = cm::occlusionPrepareQuad<!CONE>(cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_quadOff, a.quad.total);
-                footprintBits = reinterpret_cast<const uint16_t*>(a.quad.base)[oq.iq];             // the one 2-byte load of the lookup
+                oq = cm::occTailQuad(q, cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_mipTab, a.quad.total);
+                const uint16_t* entry = reinterpret_cast<const uint16_t*>(a.quad.base) + oq.iq;    // the one 2-byte load of the lookup
+                asm volatile("global_load_ushort %0, %1, off" : "=v"(footprintBits) : "v"(entry) : "memory");
             }
             if (OCCLUSION && !TABLE) {
-                os = cm::occlusionPrepare(cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_quadOff);
-                row0 = cm::loadTexelPair(a.hzb.base, os.i0);
-                row1 = cm::loadTexelPair(a.hzb.base, os.i1);
+                os = cm::occTailTexel(q, cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_quadOff);
+                const _Float16* t0 = a.hzb.base + os.i0;                                          // two texel pairs (cm::loadTexelPair)
+                const _Float16* t1 = a.hzb.base + os.i1;
+                asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "=&v"(row0), "=&v"(row1) : "v"(t0), "v"(t1) : "memory");
             }
-            TR_STAMP(3);   // occlusion prepare + texel load issue
-            {                                                                                      // prefetch step s+2 into this slot (past the
-                const uint32_t rn = r + 4 < kBatch ? r + 4 : kBatch - 1;                           //  end: a harmless re-read, keeps loads unconditional)
-                slot = loadMeshletChunks(a.meshlets, s_rec[rn].meshletBase, s_rec[rn].count, sub);
-            }
-            if (CONE)                                                                              // :90-108
-            {
-                float q = 0.0f;                                                                    // :79 rides along with the cone's divisions
-                vis &= !cm::coneBackfacingP(cone, cv, rad, adjugateOf(ri), VR, a.k.m_NearPlane, cv.z - rad, &q);
-                if (OCCLUSION && TABLE) oq.depthSphere = q;
-            }
+            TR_STAMP(3);   // quotients + footprint + lookup issue
+            // prefetch step s+2 into this slot (past the batch: the padding entries, a harmless re-read of meshlet 0 that
+            // keeps the loads unconditional).  The slot's LDS reads above have returned: their values were used.
+            issueMeshletLoads(slot, s_rec[r + 4].first, s_rec[r + 4].count, sub);
+            if (CONE)                                                                              // :104-108
+                vis &= !cm::coneTail(q, cv, rad, VR);
             TR_STAMP(4);   // prefetch issue + cone
-            if (OCCLUSION && !TABLE)
+            if (OCCLUSION && !TABLE) {
+                asm volatile("s_waitcnt vmcnt(2)" : "+v"(row0), "+v"(row1) :: "memory");         // lookup landed, prefetch in flight
                 vis &= cm::occlusionResolve(os, row0, row1);
+            }
             if (OCCLUSION && TABLE) {
-                // Issue order: table load -> prefetch -> cone ALU -> first use of the table entry.  vmcnt is in order,
-                // so the entry is awaited with vmcnt(2) while the prefetch stays in flight, and its latency hides under
-                // the cone test.  The empty asm makes the entry "depend" on the cone result: without it the scheduler
-                // converts the entry (and waits for it) before the cone test.
-                if (CONE) {
-                    const uint32_t coneDone = vis ? 1u : 0u;
-                    asm volatile("" : "+v"(footprintBits) : "v"(coneDone));
-                }
+                // Issue order: table load -> prefetch -> cone ALU -> first use of the table entry: its latency hides
+                // under the cone tail (and the other waves).  The wait is tied to the register and to the cone result.
+                const uint32_t coneDone = vis ? 1u : 0u;
+                asm volatile("s_waitcnt vmcnt(2)" : "+v"(footprintBits) : "v"(coneDone) : "memory");
                 const float footprintMin = (float)__builtin_bit_cast(_Float16, (uint16_t)footprintBits);
                 const bool visO = oq.accept | (oq.depthSphere >= footprintMin);                    // :81
-                // A lookup whose footprint is NOT the table's (a zero bilinear weight) is only noted here -- LDS
-                // traffic, no memory loads in the branch, so the loop's vmcnt bookkeeping stays exact -- and the
+                // A lookup whose footprint is NOT the table's (a zero bilinear weight) is only noted here and the
                 // meshlet is re-evaluated with the texel path after the batch (fixups below).  Rare.
                 if (__builtin_expect(__ballot(oq.slow) != 0ull, 0)) {
                     if (oq.slow) {
                         const uint32_t idx = atomicAdd(&s_slowCount[wave], 1u);
-                        if (idx < kSlowCap) s_slow[idx] = (r << 5) | myMeshlet;
+                        if (idx < kSlowCap) s_slow[idx] = (r << 5) | sub;
                     }
                 }
                 vis &= visO;
             }
-            TR_STAMP(5);   // texel wait + resolve
-            const unsigned long long ballot = __ballot(vis);                        // :116,120 WavePrefix/ActiveCountBits
-            // even lanes tested meshlets 0-15, odd lanes 16-31: put the bits back in meshlet order
-            const uint32_t lo16 = compressEvenBits(ballot), hi16 = compressEvenBits(ballot >> 1);
-            const uint32_t mask = half ? ((lo16 >> 16) | (hi16 & 0xFFFF0000u)) : ((lo16 & 0xFFFFu) | (hi16 << 16));
-            if (sub == 0) s_mask[r] = mask;             // LDS: the loop itself issues no stores (they would count in vmcnt on gfx9)
+            TR_STAMP(5);   // lookup wait + resolve
+            // :116,120 WavePrefix/ActiveCountBits: lanes 0-31 ran record 2s, lanes 32-63 record 2s+1, in meshlet order
+            const unsigned long long ballot = __ballot(vis);
+            const uint32_t mask = half ? (uint32_t)(ballot >> 32) : (uint32_t)ballot;
+            if (sub == 0) s_mask[r] = mask;             // LDS: the loop issues no stores to memory
             TR_STAMP(6);   // ballot + mask store
         };
 #pragma unroll 1
         for (uint32_t s = 0; s < nSteps; s += 2) {
-            step(slotA, s);
-            step(slotB, s + 1);
+            step(ringA, s);
+            step(ringB, s + 1);
         }
+        TR_WAIT_VMCNT(0);                               // the last two (padding) prefetches: nothing may land in the ring later
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (OCCLUSION && TABLE) {
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
                 auto exactVisible = [&](uint32_t r, uint32_t m) -> bool {
                     const RecordInfo& ri = s_rec[r];
                     if (m >= ri.count) return false;
-                    const float4* p = reinterpret_cast<const float4*>(a.meshlets + ri.meshletBase);
+                    const float4* p = reinterpret_cast<const float4*>(ri.first);
                     const float4 sphere = p[2u * m];
                     const uint32_t cone = __float_as_uint(p[2u * m + 1u].x);
                     const cm::F3 cv = cm::toViewP(cm::mulPointP({ sphere.x, sphere.y, sphere.z }, worldOf(ri)), VP);
@@ -389,7 +395,7 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
                     if (FRUSTUM) vis &= cm::frustumVisible(cv, rad, a.k.m_Frustum.x, a.k.m_Frustum.y, a.k.m_Frustum.z, a.k.m_Frustum.w);
                     vis &= cm::occlusionVisible(cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb);
                     float unused;
-                    if (CONE) vis &= !cm::coneBackfacingP(cone, cv, rad, adjugateOf(ri), VR, 1.0f, 1.0f, &unused);
+                    if (CONE) vis &= !cm::coneBackfacingP(cone, cv, rad, adjugateOf(ri), VR, 1.0f, 1.0f, &unused);   // the exact sequences
                     return vis;
                 };
                 if (nSlow <= kSlowCap) {                                             // patch single bits
@@ -889,7 +895,8 @@ int recordASMain(trhip::DispatchCtx& ctx)
     const uint64_t lcap = visList->byteSize / 4;
     a.listCapacity = lcap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)lcap;
     a.drawArgs = (uint32_t*)drawArgs->ptr;
-    if (records->sidecar && records->sidecarBytes >= 256 + (uint64_t)a.recordCapacity * 16) {
+    static const bool noPerm = getenv("TRHIP_AS_NO_PERM") != nullptr;                // experiments: process the records in list order
+    if (!noPerm && records->sidecar && records->sidecarBytes >= 256 + (uint64_t)a.recordCapacity * 16) {
         a.permHeader = (const uint32_t*)records->sidecar;
         a.perm = (const uint4*)(a.permHeader + 64);
     }
@@ -904,7 +911,9 @@ int recordASMain(trhip::DispatchCtx& ctx)
 
     // Persistent grid: the group count lives on the device (indirect), so launch enough
     // workgroups to fill the chip and let them stride over the chunks.
-    uint32_t blocksPerCU = 4u;                     // measured best with the table path (3/4/5: 0.900/0.880/0.885 ms per frame); up to 6 fit
+    // 3 workgroups per CU: what the LDS allows (47 KB each: 30 KB of per-record data + 16 KB of staged MeshletData) and
+    // also the measured optimum (2: 0.572 ms, 3: 0.528 ms on C3; 4 do not fit and would run as a second round).
+    uint32_t blocksPerCU = 3u;
     if (const char* e = getenv("TRHIP_AS_BLOCKS_PER_CU")) blocksPerCU = (uint32_t)atoi(e) ? (uint32_t)atoi(e) : blocksPerCU;   // tuning experiments
     uint32_t grid = ctx.computeUnits() * blocksPerCU;
     const uint32_t needBlocks = (a.maxBatches + kWaves - 1) / kWaves;
@@ -1049,7 +1058,7 @@ trhip::ShaderRegistrar r2("basepass_AS_Main_cull", recordASMain, 0);
 
 } // namespace
 
-#if defined(TR_STAMPS) || defined(TR_COUNT_SLOW)
+#if defined(TR_STAMPS) || defined(TR_COUNT_SLOW) || defined(TR_COUNT_PATHS)
 extern "C" int trhip_debug_read_stamps(unsigned long long* out, int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stampSums), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
