@@ -15,6 +15,8 @@ if len(starts) < nframes + 1:
 a, b = starts[-nframes - 1], starts[-1]
 t0 = k[a][0]
 for s, e, name, q, st in k[a:b]:
-    short = name.split("(")[0][-60:]
+    import re
+    mm = re.search(r"(\w+(?:<[^()]*>)?)\(", name.replace("(anonymous namespace)::", ""))
+    short = (mm.group(1) if mm else name)[-60:]
     print(f"{(s - t0) / 1e3:9.1f} {(e - t0) / 1e3:9.1f}  dur {(e - s) / 1e3:7.1f} us  q{q} s{st}  {short}")
 print("frame span us:", (k[b][0] - t0) / 1e3 / nframes)

@@ -282,15 +282,21 @@ __device__ __forceinline__ bool occlusionResolve(const OccSample& o, uint32_t ro
 
 // Footprint-min table of an HZB (built by k_hzb.hip next to the mip chain): entry (x0+1, y0+1) of mip k holds
 // the min over the 2x2 edge-clamped footprint whose origin floor(uv*dim - 0.5) is (x0, y0), x0 in [-1, w-1].
+// Entries are stored in 8 x 8 blocks (one cache line each), ((w_k >> 3) + 1) blocks per block row.
 struct HzbQuad
 {
     const _Float16* base;
     uint32_t total;
-    uint32_t offset[16];    // first entry of mip k; row stride w_k + 1
+    uint32_t offset[16];    // first entry of mip k
 };
+__device__ __forceinline__ uint32_t quadIndex(uint32_t offset, uint32_t blockRowStride /* 64 * blocks per row */, uint32_t X, uint32_t Y)
+{
+    // offset + ((Y >> 3) * blocksPerRow + (X >> 3)) * 64 + (Y & 7) * 8 + (X & 7)
+    return offset + (__umul24(Y >> 3, blockRowStride) + ((Y << 3) & 56u)) + __umul24(X >> 3, 56u) + X;
+}
 
-// culling.hlsli:36-82 for the hot kernel: same arithmetic as occlusionPrepare up to the footprint origin, then
-// ONE table entry instead of up to four texels.  The table entry equals the footprint minimum exactly when both
+// culling.hlsli:36-82 for the hot kernel (occTailQuad): same arithmetic as occlusionPrepare up to the footprint origin,
+// then ONE table entry instead of up to four texels.  The table entry equals the footprint minimum exactly when both
 // bilinear weights of both axes are non-zero; `slow` flags the other lookups (a fractional coordinate that is
 // an exact integer), which the caller resolves with the texel path.
 struct OccQuad
@@ -300,51 +306,6 @@ struct OccQuad
     float depthSphere;        // :79
     uint32_t iq;              // table index (always in range: uv is clamped to [0,1] and NaN-free)
 };
-
-// DEPTH: also compute depthSphere = nearPlane / (c.z - r) here (:79); otherwise the caller pairs that division with
-// another one (coneBackfacingP) and fills the field itself.
-template <bool DEPTH = true>
-__device__ __forceinline__ OccQuad occlusionPrepareQuad(F3 c, float r, float nearPlane, float P00, float P11, const Hzb& h,
-                                                        const uint32_t* quadOff, uint32_t quadTotal)
-{
-    OccQuad o;
-    o.accept = (c.z - nearPlane) < r;                                // :48-49
-    // the x and the y half of :53-78 are the same arithmetic on different inputs: computed as (x, y) pairs
-    const v2f cxy = { c.x, c.y };
-    const v2f cr = cxy * r;                                          // :53 cr.xy
-    const float crz = c.z * r;                                       // :53 cr.z
-    const float czr2 = fma_(c.z, c.z, -(r * r));                     // :54
-    const v2f vArg = fma2(cxy, cxy, splat2(czr2));
-    const v2f vv = sqrt2(vArg);                                      // :56, :60  vx, vy
-    const v2f czz = splat2(c.z);
-    const v2f mn = div2(fma2(vv, cxy, splat2(-crz)), fma2(vv, czz, cr));    // :57, :61  minx, miny
-    const v2f mx = div2(fma2(vv, cxy, splat2(crz)), fma2(vv, czz, -cr));    // :58, :62  maxx, maxy
-    const v2f P = { P00, P11 };
-    const v2f sMin = mn * P, sMax = mx * P;                          // :64-67
-    v2f lo = { clamp_(sMin.x, -1.0f, 1.0f), clamp_(sMin.y, -1.0f, 1.0f) };       // (ax, ay)
-    v2f hi = { clamp_(sMax.x, -1.0f, 1.0f), clamp_(sMax.y, -1.0f, 1.0f) };       // (az, aw)
-    const v2f half = { 0.5f, -0.5f };
-    lo = fma2(lo, half, splat2(0.5f));                               // :70-71 ClipXYToUV
-    hi = fma2(hi, half, splat2(0.5f));
-    const v2f wh = (hi - lo) * v2f{ (float)h.width, (float)h.height };           // :73-74
-    int mip = hzbLevel(wh.x, wh.y, h.mips);                          // :75
-    const v2f uv = (lo + hi) * splat2(0.5f);                         // :78
-    uint32_t mw = (h.width >> mip) ? (h.width >> mip) : 1u;
-    uint32_t mh = (h.height >> mip) ? (h.height >> mip) : 1u;
-    const v2f f = fma2(uv, v2f{ (float)mw, (float)mh }, splat2(-0.5f));
-    const float fx = f.x, fy = f.y;
-    float flx = __builtin_floorf(fx), fly = __builtin_floorf(fy);
-    const int x0 = (int)flx, y0 = (int)fly;                          // in [-1, mw-1] x [-1, mh-1]
-    // A zero weight drops the second column (row) from the footprint; that only changes the set of texels when the
-    // second column (row) is a different texel after edge clamping, i.e. 0 <= x0 and x0 + 1 <= mw - 1.
-    const bool slowX = !((fx - flx) > 0.0f) & (x0 >= 0) & (x0 + 1 < (int)mw);
-    const bool slowY = !((fy - fly) > 0.0f) & (y0 >= 0) & (y0 + 1 < (int)mh);
-    o.slow = slowX | slowY;
-    uint32_t iq = quadOff[mip] + (uint32_t)(y0 + 1) * (mw + 1u) + (uint32_t)(x0 + 1);
-    o.iq = iq < quadTotal ? iq : quadTotal - 1u;
-    o.depthSphere = DEPTH ? div_(nearPlane, c.z - r) : 0.0f;         // :79
-    return o;
-}
 
 // culling.hlsli:36-82; returns true = visible
 __device__ __forceinline__ bool occlusionVisible(F3 c, float r, float nearPlane, float P00, float P11, const Hzb& h)
@@ -651,7 +612,7 @@ __device__ __forceinline__ v2f occClampUv(v2f m, v2f P)
 }
 
 // Footprint-min table path.  mipTab[e], e = floor(log2(max(w, h, 1))) + 1 clamped to `mips` (what v_frexp_exp returns):
-// { first table entry of mip e-1 + its row stride + 1, row stride (= mip width + 1), (float)width, (float)height }.
+// { first table entry of mip e-1, its block-row stride (64 * blocks per row), (float)width, (float)height }.
 __device__ __forceinline__ OccQuad occTailQuad(const StepQuot& q, F3 c, float r, float nearPlane, float P00, float P11, const Hzb& h,
                                                const uint4* mipTab, uint32_t quadTotal)
 {
@@ -670,15 +631,14 @@ __device__ __forceinline__ OccQuad occTailQuad(const StepQuot& q, F3 c, float r,
     const v2f f = fma2(uv, v2f{ __uint_as_float(tab.z), __uint_as_float(tab.w) }, splat2(-0.5f));
     const float flx = __builtin_floorf(f.x), fly = __builtin_floorf(f.y);
     const int x0 = (int)flx, y0 = (int)fly;                            // in [-1, mw-1] x [-1, mh-1]
-    const uint32_t iq = (uint32_t)(__mul24(y0, (int)tab.y) + x0) + tab.x;   // == offset + (y0+1) * (mw+1) + (x0+1)
-    o.iq = min(iq, quadTotal - 1u);
+    o.iq = min(quadIndex(tab.x, tab.y, (uint32_t)(x0 + 1), (uint32_t)(y0 + 1)), quadTotal - 1u);
     // A zero weight drops the second column (row) from the footprint; that only changes the set of texels when the
     // second column (row) is a different texel after edge clamping, i.e. 0 <= x0 and x0 + 1 <= mw - 1.  Rare: only a
     // wave that has an exactly integral coordinate somewhere looks at the rest of the condition.
     const bool zx = !(f.x > flx), zy = !(f.y > fly);
     o.slow = false;
     if (__builtin_expect(__ballot(zx | zy) != 0ull, 0)) {
-        const int mw = (int)tab.y - 1, mh = (int)__uint_as_float(tab.w);
+        const int mw = (int)__uint_as_float(tab.z), mh = (int)__uint_as_float(tab.w);
         o.slow = (zx & (x0 >= 0) & (x0 + 1 < mw)) | (zy & (y0 >= 0) & (y0 + 1 < mh));
     }
     o.depthSphere = q.depthSphere;

@@ -528,8 +528,13 @@ public:
         frustumY = Normalize(frustumY);
         m_CullingFrustum = Vector4{ frustumX.x, frustumX.z, frustumY.y, frustumY.z };
 
+        // Where GenerateHZB finds the frame's depth: the depth attachment the rasteriser wrote -- or, when nothing rasterises
+        // (the stand-in of the culling benchmarks and tests), the uploaded depth image itself.  (Round 1 copied the image
+        // into the attachment every frame: 33 MB and a launch for nothing.)
+        RenderBasePassParams hzbParams = params;
+        if (g_Scene->m_SyntheticDepth && !g_Scene->m_bRasterDepth) hzbParams.m_DepthBuffer = g_Scene->m_SyntheticDepth;
         m_CurrentDepthBuffer = params.m_DepthBuffer;
-        m_LastDepthBuffer = params.m_DepthBuffer;
+        m_LastDepthBuffer = hzbParams.m_DepthBuffer;
         if (g_Scene->m_bRasterDepth)                                                                 // the base pass starts from a cleared depth buffer
             commandList->clearTextureFloat(params.m_DepthBuffer, nvrhi::AllSubresources, nvrhi::Color{ GraphicConstants::kFarDepth });
 
@@ -537,9 +542,7 @@ public:
         RenderInstances(commandList, renderGraph, kEarlyOpaque, false, false);
 
         if (m_bDoOcclusionCulling) {                                                                 // :568-581
-            // stand-in for the rasteriser: the frame's depth image arrives here
-            if (g_Scene->m_SyntheticDepth && !g_Scene->m_bRasterDepth) commandList->copyTexture(params.m_DepthBuffer, g_Scene->m_SyntheticDepth);
-            GenerateHZB(commandList, renderGraph, params);
+            GenerateHZB(commandList, renderGraph, hzbParams);
 
             GPUCulling(commandList, renderGraph, kLateOpaque, true, false);
             RenderInstances(commandList, renderGraph, kLateOpaque, true, false);
@@ -550,7 +553,7 @@ public:
                 GPUCulling(commandList, renderGraph, kLateAlphaMask, true, true);
                 RenderInstances(commandList, renderGraph, kLateAlphaMask, true, true);
             }
-            GenerateHZB(commandList, renderGraph, params);
+            GenerateHZB(commandList, renderGraph, hzbParams);
         } else if (m_NumSlotsThisFrame == kNumPassSlots) {
             // cull & render for alpha mask primitives, but no occlusion culling (:583-587)
             GPUCulling(commandList, renderGraph, kEarlyAlphaMask, false, true);

@@ -12,7 +12,8 @@
 struct InstanceCullCache
 {
     const float4* sphere;           // world-space bounding sphere: TransformBoundingSphereToWorld (gpuculling.hlsl:116)
-    const float4* world;            // [id][3]: world matrix rows 0..3, xyz, as 12 consecutive floats
+    const float4* world;            // [id][4]: ONE 64-byte block per instance -- world matrix rows 0..3 (xyz) as 12 consecutive
+                                    // floats, then {maxScale, 0, 0, 0}: everything the meshlet cull reads per record
     const float* maxScale;          // toyrenderer_common.hlsli:134-140
     const uint32_t* numLODs;
     const uint32_t* numMeshlets;    // [id][kMaxNumMeshLODs]
@@ -20,14 +21,14 @@ struct InstanceCullCache
     const float* error;             // [id][kMaxNumMeshLODs]
 };
 
-constexpr uint64_t kInstanceCacheBytesPerInstance = 16 + 48 + 4 + 4 + 3 * 4 * interop::kMaxNumMeshLODs;
+constexpr uint64_t kInstanceCacheBytesPerInstance = 64 + 16 + 4 + 4 + 3 * 4 * interop::kMaxNumMeshLODs;
 
 inline InstanceCullCache instanceCacheLayout(void* base, uint64_t n)
 {
     char* p = (char*)base;
     InstanceCullCache c;
+    c.world = (const float4*)p;             p += 64 * n;          // first: 64-byte aligned blocks
     c.sphere = (const float4*)p;            p += 16 * n;
-    c.world = (const float4*)p;             p += 48 * n;
     c.maxScale = (const float*)p;           p += 4 * n;
     c.numLODs = (const uint32_t*)p;         p += 4 * n;
     c.numMeshlets = (const uint32_t*)p;     p += 4ull * interop::kMaxNumMeshLODs * n;

@@ -51,6 +51,16 @@ constexpr uint32_t kBlock = 256;
 constexpr uint32_t kWaves = kBlock / 64;
 constexpr uint32_t kBatch = 64;                  // records per wave batch
 constexpr uint32_t kSteps = kBatch / 2;          // two records per wave step
+#ifndef TR_CULL_BATCH
+#define TR_CULL_BATCH 32     /* 64: 47 KB of LDS per workgroup, 3 per CU, 0.511 ms on C3; 32: 34 KB, 4 per CU, 0.482 ms; 16: 0.498 ms */
+#endif
+constexpr uint32_t kCullBatch = TR_CULL_BATCH;   // meshlet cull: records a wave resolves per prologue (<= 64: one per lane)
+constexpr uint32_t kCullSteps = kCullBatch / 2;
+#ifndef TR_CULL_WAVES
+#define TR_CULL_WAVES 4
+#endif
+constexpr uint32_t kCullWaves = TR_CULL_WAVES;   // meshlet cull: waves per workgroup (= per window of 64 * kCullWaves... records)
+constexpr uint32_t kCullBlock = 64 * kCullWaves;
 constexpr uint32_t kSlowCap = 64;                // per wave and batch: lookups deferred to the texel path (see OccQuad::slow)
 
 struct RecordInfo                                 // per-record invariants parked in LDS (112 B, read as 128-bit words)
@@ -96,7 +106,7 @@ struct MeshletCullArgs
     // optional processing order written by the instance pass into the record buffer's sidecar
     // (k_gpuculling.hip): {valid, count} header + a permutation of [0, count) sorted by screen tile
     const uint32_t* permHeader;
-    const uint4* perm;                            // {record index, instance, lod, group offset} in processing order
+    const uint4* perm;                            // {record index, instance, first meshlet, count} in processing order
     InstanceCullCache cache;                      // world matrix, max scale, LOD table per instance (instance_cache.hip.h)
     uint32_t numInstances;
 };
@@ -155,21 +165,21 @@ __device__ __forceinline__ void issueMeshletLoads(char* slotLds /* wave-uniform 
 // table is rebuilt once per frame behind the instance pass) or through the texels themselves (two texel-pair
 // loads; the late pass, which is small and follows an HZB rebuild).  Same results either way.
 template <bool FRUSTUM, bool OCCLUSION, bool CONE, bool TABLE>
-__global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
+__global__ __launch_bounds__(kCullBlock) void meshletCullKernel(MeshletCullArgs a)
 {
 #ifdef TR_STAMPS
     unsigned long long stampSum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stampLast = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-    __shared__ RecordInfo s_recAll[kWaves][kBatch + 4];           // + 4: the prefetch of the last two steps reads past the batch (count 0)
-    __shared__ uint32_t s_gIdxAll[kWaves][kBatch];
+    __shared__ RecordInfo s_recAll[kCullWaves][kCullBatch + 4];           // + 4: the prefetch of the last two steps reads past the batch (count 0)
+    __shared__ uint32_t s_gIdxAll[kCullWaves][kCullBatch];
     __shared__ uint32_t s_quadOff[16];                 // texel path: mip offsets
     __shared__ uint4 s_mipTab[17];                     // table path: per-mip constants indexed by exponent + 1 (cm::occTailQuad)
-    __shared__ uint32_t s_slowAll[kWaves][kSlowCap];
-    __shared__ uint32_t s_slowCount[kWaves];
-    __shared__ uint32_t s_maskAll[kWaves][kBatch];
-    __shared__ __attribute__((aligned(16))) char s_ring[kWaves][2][2048];   // per wave: two ring slots of staged MeshletData
+    __shared__ uint32_t s_slowAll[kCullWaves][kSlowCap];
+    __shared__ uint32_t s_slowCount[kCullWaves];
+    __shared__ uint32_t s_maskAll[kCullWaves][kCullBatch];
+    __shared__ __attribute__((aligned(16))) char s_ring[kCullWaves][2][2048];   // per wave: two ring slots of staged MeshletData
 
     const uint32_t G = groupCount(a);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -184,37 +194,38 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
     if (TABLE && tid >= 1 && tid <= 16) {
         const uint32_t mip = tid - 1u < a.hzb.mips ? tid - 1u : 0u;
         const uint32_t mw = (a.hzb.width >> mip) ? (a.hzb.width >> mip) : 1u, mh = (a.hzb.height >> mip) ? (a.hzb.height >> mip) : 1u;
-        s_mipTab[tid] = make_uint4(a.quad.offset[mip] + mw + 2u, mw + 1u, __float_as_uint((float)mw), __float_as_uint((float)mh));
+        s_mipTab[tid] = make_uint4(a.quad.offset[mip], ((mw >> 3) + 1u) * 64u, __float_as_uint((float)mw), __float_as_uint((float)mh));
     }
     // the fast arithmetic path wants nearPlane in [2^-20, 2^20] (cm::stepQuotients)
     const bool nearInRange = a.k.m_NearPlane >= 0x1p-20f && a.k.m_NearPlane <= 0x1p20f;
-    if (tid < kWaves) s_slowCount[tid] = 0;
-    if (lane < 4) { s_recAll[wave][kBatch + lane].first = a.meshlets; s_recAll[wave][kBatch + lane].count = 0; }
+    if (tid < kCullWaves) s_slowCount[tid] = 0;
+    if (lane < 4) { s_recAll[wave][kCullBatch + lane].first = a.meshlets; s_recAll[wave][kCullBatch + lane].count = 0; }
     uint32_t* s_slow = s_slowAll[wave];
     uint32_t* s_mask = s_maskAll[wave];
     __syncthreads();                                                                 // the only workgroup barrier
 
     // Work decomposition.  Records are processed in screen-tile order when the instance pass published one for exactly
     // this record count (any permutation of [0,G) is a valid processing order: masks are stored by record index);
-    // otherwise in record order.  The order is cut into WINDOWS of 64 * kWaves = 256 consecutive records; workgroup b takes
-    // windows b, b + gridDim, ...; inside a window, wave w runs records {2 * kWaves * s + 2 * w + half} at step s.  The
+    // otherwise in record order.  The order is cut into WINDOWS of 64 * kCullWaves = 256 consecutive records; workgroup b takes
+    // windows b, b + gridDim, ...; inside a window, wave w runs records {2 * kCullWaves * s + 2 * w + half} at step s.  The
     // waves of a workgroup thus stay inside 256 consecutive records (in tile order: a few dozen instances of one screen
     // region) for a whole batch, and the HZB lookups of a CU keep hitting the same few table rows in its L1.
     // (Round 1 walked ONE window of 2 * numWaves records with all waves of the chip -- good for the L2s, but every CU then
     // touched a different screen region at every step and 3 of 4 lookups missed its L1: -DTR_TEAM_ALL, 3 % slower.)
     const bool usePerm = a.permHeader != nullptr && a.permHeader[0] == 1u && a.permHeader[1] == G;
 #ifndef TR_TEAM_ALL
-    const uint32_t teamWaves = kWaves, waveInTeam = wave, team = blockIdx.x, teams = gridDim.x;
+    const uint32_t teamWaves = kCullWaves, waveInTeam = wave, team = blockIdx.x, teams = gridDim.x;
 #else
-    const uint32_t teamWaves = gridDim.x * kWaves, waveInTeam = blockIdx.x * kWaves + wave, team = 0u, teams = 1u;
+    const uint32_t teamWaves = gridDim.x * kCullWaves, waveInTeam = blockIdx.x * kCullWaves + wave, team = 0u, teams = 1u;
 #endif
-    const uint32_t superSize = teamWaves * kBatch;
+    const uint32_t superSize = teamWaves * kCullBatch;
     const uint32_t numSuper = (G + superSize - 1) / superSize;
-    // The batch entry of lane l = the record of step l/2, half l&1, as {record index, instance, lod, group offset}
-    // (0xFFFFFFFF = none): from the permuted copy the instance pass wrote, or from the record buffer itself.
+    // The batch entry of lane l = the record of step l/2, half l&1 (0xFFFFFFFF = none): {record index, instance, first
+    // meshlet, count} from the tile-ordered list the instance pass wrote, or {record index, instance, lod, group offset}
+    // from the record buffer itself.
     auto loadEntry = [&](uint32_t sb_) -> uint4 {
         const uint64_t e64 = (uint64_t)sb_ * superSize + (lane >> 1) * 2 * teamWaves + 2 * waveInTeam + (lane & 1);
-        if (sb_ >= numSuper || e64 >= G) return make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+        if (lane >= kCullBatch || sb_ >= numSuper || e64 >= G) return make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
         const uint32_t e = (uint32_t)e64;
         if (usePerm) return a.perm[e];
         const MeshletAmplificationData rec = a.records[e];
@@ -227,7 +238,7 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
         // steps of this window that still hold records for this wave (wave-uniform), rounded up to even
         const uint32_t remaining = G - sbBase - 2 * waveInTeam;
         uint32_t nSteps = (remaining + 2 * teamWaves - 1) / (2 * teamWaves);
-        nSteps = nSteps < kSteps ? (nSteps + 1u) & ~1u : kSteps;
+        nSteps = nSteps < kCullSteps ? (nSteps + 1u) & ~1u : kCullSteps;
         TR_STAMP(0);   // between batches
         // ---- prologue: lane l resolves its record (basepass.hlsl:52-58) through the instance cull cache: ONE
         //      level of dependent loads here -- the entry itself was fetched while the previous batch ran ------
@@ -246,34 +257,38 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
             const uint4 cur = entry;
             entry = loadEntry(sb + teams);                                           // next batch's entry: in flight during this batch
             const uint32_t g = cur.x < G ? cur.x : 0xFFFFFFFFu;
-            s_gIdx[lane] = g;
+            if (lane < kCullBatch) s_gIdx[lane] = g;
             if (g < G) {
                 const uint32_t cid = cur.y < a.numInstances ? cur.y : 0u;            // never read outside the cache
-                const float4* wr = a.cache.world + 3ull * cid;
-                const float4 q0 = wr[0], q1 = wr[1], q2 = wr[2];
-                const uint32_t lodIdx = cur.z < kMaxNumMeshLODs ? cur.z : kMaxNumMeshLODs - 1u;
-                const uint32_t lodNumMeshlets = a.cache.numMeshlets[(uint64_t)cid * kMaxNumMeshLODs + lodIdx];
-                const uint32_t lodMeshletBase = a.cache.meshletBase[(uint64_t)cid * kMaxNumMeshLODs + lodIdx];
+                const float4* wr = a.cache.world + 4ull * cid;                       // one 64-byte block: world rows + max scale
+                const float4 q0 = wr[0], q1 = wr[1], q2 = wr[2], q3 = wr[3];
                 const cm::F3 r0 = { q0.x, q0.y, q0.z }, r1 = { q0.w, q1.x, q1.y }, r2 = { q1.z, q1.w, q2.x };
                 ri.wxy[0] = r0.x; ri.wxy[1] = r0.y; ri.wz[0] = r0.z;
                 ri.wxy[2] = r1.x; ri.wxy[3] = r1.y; ri.wz[1] = r1.z;
                 ri.wxy[4] = r2.x; ri.wxy[5] = r2.y; ri.wz[2] = r2.z;
                 ri.wxy[6] = q2.y; ri.wxy[7] = q2.z; ri.wz[3] = q2.w;
-                ri.maxScale = a.cache.maxScale[cid];                                 // toyrenderer_common.hlsli:134-140 (cached)
+                ri.maxScale = q3.x;                                                  // toyrenderer_common.hlsli:134-140 (cached)
                 const cm::F3 a0 = cm::cross3(r1, r2), a1 = cm::cross3(r2, r0), a2 = cm::cross3(r0, r1); // :124-132
                 ri.adjxy[0] = a0.x; ri.adjxy[1] = a0.y; ri.adjz[0] = a0.z;
                 ri.adjxy[2] = a1.x; ri.adjxy[3] = a1.y; ri.adjz[1] = a1.z;
                 ri.adjxy[4] = a2.x; ri.adjxy[5] = a2.y; ri.adjz[2] = a2.z;
-                // lanes with meshletIdx = groupOffset + lane < numMeshlets (basepass.hlsl:62-63)
-                const uint32_t off = cur.w;
-                uint32_t cnt = lodNumMeshlets > off ? lodNumMeshlets - off : 0u;
+                // lanes with meshletIdx = groupOffset + lane < numMeshlets (basepass.hlsl:62-63): {first meshlet, count}
+                // already resolved by the instance pass (tile-ordered list), or through the LOD table here
+                uint64_t base = cur.z;
+                uint32_t cnt = cur.w;
+                if (!usePerm) {
+                    const uint32_t lodIdx = cur.z < kMaxNumMeshLODs ? cur.z : kMaxNumMeshLODs - 1u;
+                    const uint32_t lodNumMeshlets = a.cache.numMeshlets[(uint64_t)cid * kMaxNumMeshLODs + lodIdx];
+                    const uint32_t off = cur.w;
+                    cnt = lodNumMeshlets > off ? lodNumMeshlets - off : 0u;
+                    base = (uint64_t)a.cache.meshletBase[(uint64_t)cid * kMaxNumMeshLODs + lodIdx] + off;
+                }
                 cnt = cnt < 32u ? cnt : 32u;
-                const uint64_t base = (uint64_t)lodMeshletBase + off;
                 if (base + cnt > a.numMeshlets) cnt = 0;                             // never read outside the meshlet buffer
                 ri.count = cnt;
                 if (cnt) ri.first = a.meshlets + base;
             }
-            s_rec[lane] = ri;
+            if (lane < kCullBatch) s_rec[lane] = ri;
         }
         // LDS traffic of one wave is executed in order: the wave-level fence only stops the
         // compiler from moving the reads below above the writes above.
@@ -315,33 +330,37 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
             cm::OccQuad oq;
             cm::OccSample os;
             uint32_t footprintBits = 0, row0 = 0, row1 = 0;
+            if (CONE)                                                                              // :104-108
+                vis &= !cm::coneTail(q, cv, rad, VR);
+            TR_STAMP(3);   // quotients + cone
             if (OCCLUSION && TABLE) {                                                              // :75-88 (Q4)
                 oq = cm::occTailQuad(q, cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_mipTab, a.quad.total);
-                const uint16_t* entry = reinterpret_cast<const uint16_t*>(a.quad.base) + oq.iq;    // the one 2-byte load of the lookup
-                asm volatile("global_load_ushort %0, %1, off" : "=v"(footprintBits) : "v"(entry) : "memory");
+                // The one 2-byte load of the lookup -- only for the lanes whose meshlet is still in the race and not
+                // accepted at the near plane (:48-49): the tests are pure, so skipping a lookup whose result cannot
+                // matter changes nothing, and a third fewer scattered requests reach the L1 (the kernel's bottleneck).
+                const uint16_t* entry = reinterpret_cast<const uint16_t*>(a.quad.base) + oq.iq;
+                if (vis & !oq.accept)
+                    asm volatile("global_load_ushort %0, %1, off" : "+v"(footprintBits) : "v"(entry) : "memory");
             }
             if (OCCLUSION && !TABLE) {
                 os = cm::occTailTexel(q, cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_quadOff);
                 const _Float16* t0 = a.hzb.base + os.i0;                                          // two texel pairs (cm::loadTexelPair)
                 const _Float16* t1 = a.hzb.base + os.i1;
-                asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "=&v"(row0), "=&v"(row1) : "v"(t0), "v"(t1) : "memory");
+                if (vis & !os.accept)
+                    asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "+v"(row0), "+v"(row1) : "v"(t0), "v"(t1) : "memory");
             }
-            TR_STAMP(3);   // quotients + footprint + lookup issue
             // prefetch step s+2 into this slot (past the batch: the padding entries, a harmless re-read of meshlet 0 that
             // keeps the loads unconditional).  The slot's LDS reads above have returned: their values were used.
             issueMeshletLoads(slot, s_rec[r + 4].first, s_rec[r + 4].count, sub);
-            if (CONE)                                                                              // :104-108
-                vis &= !cm::coneTail(q, cv, rad, VR);
-            TR_STAMP(4);   // prefetch issue + cone
+            TR_STAMP(4);   // lookup + prefetch issue
+            // Loads are counted in order: "at most 2 outstanding" = everything before this step's prefetch has landed,
+            // whether or not the wave issued its lookup.
             if (OCCLUSION && !TABLE) {
-                asm volatile("s_waitcnt vmcnt(2)" : "+v"(row0), "+v"(row1) :: "memory");         // lookup landed, prefetch in flight
+                asm volatile("s_waitcnt vmcnt(2)" : "+v"(row0), "+v"(row1) :: "memory");
                 vis &= cm::occlusionResolve(os, row0, row1);
             }
             if (OCCLUSION && TABLE) {
-                // Issue order: table load -> prefetch -> cone ALU -> first use of the table entry: its latency hides
-                // under the cone tail (and the other waves).  The wait is tied to the register and to the cone result.
-                const uint32_t coneDone = vis ? 1u : 0u;
-                asm volatile("s_waitcnt vmcnt(2)" : "+v"(footprintBits) : "v"(coneDone) : "memory");
+                asm volatile("s_waitcnt vmcnt(2)" : "+v"(footprintBits) :: "memory");
                 const float footprintMin = (float)__builtin_bit_cast(_Float16, (uint16_t)footprintBits);
                 const bool visO = oq.accept | (oq.depthSphere >= footprintMin);                    // :81
                 // A lookup whose footprint is NOT the table's (a zero bilinear weight) is only noted here and the
@@ -418,8 +437,8 @@ __global__ __launch_bounds__(kBlock) void meshletCullKernel(MeshletCullArgs a)
         }
         // ---- the batch's 64 masks leave in one store (lane l: record l of the batch) ----------------------------
         {
-            const uint32_t g = s_gIdx[lane];
-            if (g < G && (lane >> 1) < nSteps) a.visMask[g] = s_mask[lane];
+            const uint32_t g = lane < kCullBatch ? s_gIdx[lane] : 0xFFFFFFFFu;
+            if (g < G && (lane >> 1) < nSteps) a.visMask[g] = s_mask[lane < kCullBatch ? lane : 0u];
         }
     }
 #ifdef TR_STAMPS
@@ -825,8 +844,8 @@ void emitListBuild(const trhip::DispatchCtx& ctx, const MeshletCullArgs& a, cons
 template <bool F, bool O, bool C>
 void launchCull(const MeshletCullArgs& a, uint32_t grid, bool table, hipStream_t s)
 {
-    if (O && table) hipLaunchKernelGGL((meshletCullKernel<F, O, C, true>), dim3(grid), dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL((meshletCullKernel<F, O, C, false>), dim3(grid), dim3(kBlock), 0, s, a);
+    if (O && table) hipLaunchKernelGGL((meshletCullKernel<F, O, C, true>), dim3(grid), dim3(kCullBlock), 0, s, a);
+    else hipLaunchKernelGGL((meshletCullKernel<F, O, C, false>), dim3(grid), dim3(kCullBlock), 0, s, a);
 }
 
 int recordASMain(trhip::DispatchCtx& ctx)
@@ -911,12 +930,12 @@ int recordASMain(trhip::DispatchCtx& ctx)
 
     // Persistent grid: the group count lives on the device (indirect), so launch enough
     // workgroups to fill the chip and let them stride over the chunks.
-    // 3 workgroups per CU: what the LDS allows (47 KB each: 30 KB of per-record data + 16 KB of staged MeshletData) and
-    // also the measured optimum (2: 0.572 ms, 3: 0.528 ms on C3; 4 do not fit and would run as a second round).
-    uint32_t blocksPerCU = 3u;
+    // As many workgroups per CU as the LDS allows (34 KB each: 16 KB of per-record data + 16 KB of staged MeshletData):
+    // the kernel's pace is set by the bytes it keeps in flight (2 ring slots x 2 KB per wave), see issueMeshletLoads.
+    uint32_t blocksPerCU = 4u;
     if (const char* e = getenv("TRHIP_AS_BLOCKS_PER_CU")) blocksPerCU = (uint32_t)atoi(e) ? (uint32_t)atoi(e) : blocksPerCU;   // tuning experiments
     uint32_t grid = ctx.computeUnits() * blocksPerCU;
-    const uint32_t needBlocks = (a.maxBatches + kWaves - 1) / kWaves;
+    const uint32_t needBlocks = (a.recordCapacity + kCullBatch * kCullWaves - 1) / (kCullBatch * kCullWaves);
     if (grid > needBlocks) grid = needBlocks;
     if (grid == 0) grid = 1;
     const uint32_t flags = k->m_CullingFlags & 7u;

@@ -62,7 +62,7 @@ struct InstanceCullArgs
     uint32_t tileReplicas;          // kTileReplicas or kTileReplicasSmall
     uint16_t* tileOf;               // per entry
     uint32_t* permHeader;
-    uint4* perm;                    // {record index, instance, lod, group offset}: the record itself, in processing order
+    uint4* perm;                    // {record index, instance, first meshlet, meshlets in the group}: the record RESOLVED, in processing order
     uint32_t permCapacity;
     uint32_t* lateArgsOut;          // early, optional: gpuculling_CS_BuildLateCullIndirectArgs folded into the scan (recordBuildLateArgs)
     // small passes (instanceFusedKernel): one status line per tile of 256 entries + the ticket counter, zeroed per launch
@@ -103,10 +103,11 @@ __global__ __launch_bounds__(256) void instanceCacheKernel(const BasePassInstanc
     const float ms = cm::maxScale(W.r0, W.r1, W.r2);
     const cm::F3 wc = cm::mulPoint({ sph.x, sph.y, sph.z }, W);                      // :116 TransformBoundingSphereToWorld
     const_cast<float4*>(c.sphere)[i] = make_float4(wc.x, wc.y, wc.z, sph.w * ms);
-    float4* wr = const_cast<float4*>(c.world) + 3ull * i;
+    float4* wr = const_cast<float4*>(c.world) + 4ull * i;
     wr[0] = make_float4(w0.x, w0.y, w0.z, w1.x);
     wr[1] = make_float4(w1.y, w1.z, w2.x, w2.y);
     wr[2] = make_float4(w2.z, w3.x, w3.y, w3.z);
+    wr[3] = make_float4(ms, 0.f, 0.f, 0.f);
     const_cast<float*>(c.maxScale)[i] = ms;
     const_cast<uint32_t*>(c.numLODs)[i] = numLODs;
 #pragma unroll
@@ -385,8 +386,16 @@ __global__ __launch_bounds__(kBlock) void instanceEmitKernel(InstanceCullArgs a)
     }
     if (groups != 0 && n >= kMinBinnedEntries) {                                    // slot range in the tile-sorted order
         const uint32_t p = atomicAdd(&a.tileCount[(uint32_t)a.tileOf[t] * a.tileReplicas + (blockIdx.x % a.tileReplicas)], groups);
-        for (uint32_t i = 0; i < groups; ++i)
-            if (p + i < a.permCapacity) a.perm[p + i] = make_uint4(off + i, id, lod, i * kNumThreadsPerWave);
+        // the record resolved through the LOD table here, once per instance (basepass.hlsl:54-63): the meshlet cull then
+        // reads 16 bytes of this list and one 64-byte block of the instance cache per record, nothing else
+        const uint32_t cid = id < a.numInstances ? id : 0u;
+        const uint32_t numMeshlets = a.cache.numMeshlets[(uint64_t)cid * kMaxNumMeshLODs + lod];
+        const uint32_t base = a.cache.meshletBase[(uint64_t)cid * kMaxNumMeshLODs + lod];
+        for (uint32_t i = 0; i < groups; ++i) {
+            const uint32_t first = i * kNumThreadsPerWave;
+            const uint32_t cnt = numMeshlets > first ? (numMeshlets - first < kNumThreadsPerWave ? numMeshlets - first : kNumThreadsPerWave) : 0u;
+            if (p + i < a.permCapacity) a.perm[p + i] = make_uint4(off + i, id, base + first, cnt);
+        }
     }
 }
 

@@ -218,6 +218,10 @@ __global__ __launch_bounds__(1024) void spdTailKernel(SpdArgs a, uint32_t first)
 // the texels {clamp(X-1), clamp(X)} x {clamp(Y-1), clamp(Y)} -- the footprint of a bilinear lookup whose
 // origin floor(uv*dim - 0.5) is (X-1, Y-1) and whose two weights per axis are non-zero (culling.hlsli:78
 // with the min-reduction sampler, CommonResources.cpp:276-287).  One thread per entry, all mips in one launch.
+// Layout: 8 x 8 BLOCKS of entries (64 x 2 B = one 128-byte cache line per block), blocks row-major, ((w >> 3) + 1) per
+// block row: the lookups of the meshlet cull scatter over a 2-D screen region, and a region covers 2-4x fewer lines
+// this way than with row-major entries (a line = 64 x 1 texels).  Entry (X, Y) of mip k sits at
+// quadOffset[k] + ((Y >> 3) * blocksPerRow + (X >> 3)) * 64 + (Y & 7) * 8 + (X & 7); blocks past the edge are padding.
 struct QuadArgs
 {
     const _Float16* base;
@@ -235,7 +239,9 @@ __global__ __launch_bounds__(256) void hzbQuadBuildKernel(QuadArgs a)
     for (uint32_t m = 1; m < a.mips; ++m) k += i >= a.quadOffset[m] ? 1u : 0u;
     const uint32_t mw = (a.width >> k) ? (a.width >> k) : 1u, mh = (a.height >> k) ? (a.height >> k) : 1u;
     const uint32_t j = i - a.quadOffset[k];
-    const uint32_t X = j % (mw + 1u), Y = j / (mw + 1u);
+    const uint32_t bpr = (mw >> 3) + 1u, blk = j >> 6;
+    uint32_t X = (blk % bpr) * 8u + (j & 7u), Y = (blk / bpr) * 8u + ((j >> 3) & 7u);
+    X = X < mw ? X : mw; Y = Y < mh ? Y : mh;                      // padding entries repeat the edge
     const uint32_t xa = X ? X - 1u : 0u, xb = X < mw ? X : mw - 1u;
     const uint32_t ya = Y ? Y - 1u : 0u, yb = Y < mh ? Y : mh - 1u;
     const _Float16* t = a.base + a.mipOffset[k];
@@ -370,7 +376,7 @@ int hzbQuadEnsure(trhip_texture_t* tex)
     uint64_t total = 0;
     for (uint32_t k = 0; k < tex->mips; ++k) {
         tex->quadOffset[k] = (uint32_t)total;
-        total += (uint64_t)(tex->mipW(k) + 1) * (tex->mipH(k) + 1);
+        total += (uint64_t)((tex->mipW(k) >> 3) + 1) * ((tex->mipH(k) >> 3) + 1) * 64u;      // 8 x 8 blocks, see hzbQuadBuildKernel
     }
     TRHIP_REQUIRE(total < (1ull << 31), "footprint-min table: HZB %ux%u too large", tex->width, tex->height);
     tex->quadTotal = (uint32_t)total;

@@ -132,7 +132,7 @@ struct trhip_texture_t
     // load.  It is current while quadBuiltVersion == version (see trhip_buffer_t::version).
     void* quad = nullptr;
     uint64_t quadBytes = 0;
-    uint32_t quadOffset[16] = {};              // first entry of mip k; mip k has (w_k + 1) * (h_k + 1) entries
+    uint32_t quadOffset[16] = {};              // first entry of mip k; mip k has ((w_k >> 3) + 1) * ((h_k >> 3) + 1) blocks of 8 x 8 entries
     uint32_t quadTotal = 0;
     uint64_t quadBuiltVersion = 0;
     std::atomic<uint64_t> version{1};
