@@ -16,8 +16,7 @@ struct InstanceCullCache
                                     // floats, then {maxScale, 0, 0, 0}: everything the meshlet cull reads per record
     const float* maxScale;          // toyrenderer_common.hlsli:134-140
     const uint32_t* numLODs;
-    const uint32_t* numMeshlets;    // [id][kMaxNumMeshLODs]
-    const uint32_t* meshletBase;    // [id][kMaxNumMeshLODs]  m_MeshletDataBufferIdx
+    const uint2* lodInfo;           // [id][kMaxNumMeshLODs]  {m_NumMeshlets, m_MeshletDataBufferIdx}
     const float* error;             // [id][kMaxNumMeshLODs]
 };
 
@@ -31,8 +30,7 @@ inline InstanceCullCache instanceCacheLayout(void* base, uint64_t n)
     c.sphere = (const float4*)p;            p += 16 * n;
     c.maxScale = (const float*)p;           p += 4 * n;
     c.numLODs = (const uint32_t*)p;         p += 4 * n;
-    c.numMeshlets = (const uint32_t*)p;     p += 4ull * interop::kMaxNumMeshLODs * n;
-    c.meshletBase = (const uint32_t*)p;     p += 4ull * interop::kMaxNumMeshLODs * n;
+    c.lodInfo = (const uint2*)p;            p += 8ull * interop::kMaxNumMeshLODs * n;
     c.error = (const float*)p;
     return c;
 }

@@ -278,10 +278,10 @@ __global__ __launch_bounds__(kCullBlock) void meshletCullKernel(MeshletCullArgs 
                 uint32_t cnt = cur.w;
                 if (!usePerm) {
                     const uint32_t lodIdx = cur.z < kMaxNumMeshLODs ? cur.z : kMaxNumMeshLODs - 1u;
-                    const uint32_t lodNumMeshlets = a.cache.numMeshlets[(uint64_t)cid * kMaxNumMeshLODs + lodIdx];
+                    const uint2 li = a.cache.lodInfo[(uint64_t)cid * kMaxNumMeshLODs + lodIdx];
                     const uint32_t off = cur.w;
-                    cnt = lodNumMeshlets > off ? lodNumMeshlets - off : 0u;
-                    base = (uint64_t)a.cache.meshletBase[(uint64_t)cid * kMaxNumMeshLODs + lodIdx] + off;
+                    cnt = li.x > off ? li.x - off : 0u;
+                    base = (uint64_t)li.y + off;
                 }
                 cnt = cnt < 32u ? cnt : 32u;
                 if (base + cnt > a.numMeshlets) cnt = 0;                             // never read outside the meshlet buffer

@@ -61,6 +61,7 @@ struct InstanceCullArgs
     uint32_t* tileCount;
     uint32_t tileReplicas;          // kTileReplicas or kTileReplicasSmall
     uint16_t* tileOf;               // per entry
+    uint2* lodSel;                  // per entry: {meshlets, first meshlet} of the LOD the instance was submitted at
     uint32_t* permHeader;
     uint4* perm;                    // {record index, instance, first meshlet, meshlets in the group}: the record RESOLVED, in processing order
     uint32_t permCapacity;
@@ -112,8 +113,7 @@ __global__ __launch_bounds__(256) void instanceCacheKernel(const BasePassInstanc
     const_cast<uint32_t*>(c.numLODs)[i] = numLODs;
 #pragma unroll
     for (uint32_t l = 0; l < kMaxNumMeshLODs; ++l) {
-        const_cast<uint32_t*>(c.numMeshlets)[(uint64_t)i * kMaxNumMeshLODs + l] = nm[l];
-        const_cast<uint32_t*>(c.meshletBase)[(uint64_t)i * kMaxNumMeshLODs + l] = mb[l];
+        const_cast<uint2*>(c.lodInfo)[(uint64_t)i * kMaxNumMeshLODs + l] = make_uint2(nm[l], mb[l]);
         const_cast<float*>(c.error)[(uint64_t)i * kMaxNumMeshLODs + l] = err[l];
     }
 }
@@ -171,7 +171,7 @@ __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v, uint32_t lane)
 
 // gpuculling.hlsl:105-178 up to the ordered side effects.
 template <int LATE>
-__device__ __forceinline__ uint32_t classify(const InstanceCullArgs& a, uint32_t id, uint32_t* tileOut)
+__device__ __forceinline__ uint32_t classify(const InstanceCullArgs& a, uint32_t id, uint32_t* tileOut, uint2* lodOut)
 {
     const GPUCullingPassConstants& k = a.k;
     const bool doFrustum = (k.m_CullingFlags & kCullingFlagFrustumCullingEnable) != 0;
@@ -197,7 +197,7 @@ __device__ __forceinline__ uint32_t classify(const InstanceCullArgs& a, uint32_t
 
     // SubmitInstance :35-62
     const uint32_t numLODs = a.cache.numLODs[cid];
-    const uint32_t* lodMeshlets = a.cache.numMeshlets + (uint64_t)cid * kMaxNumMeshLODs;
+    const uint2* lodInfo = a.cache.lodInfo + (uint64_t)cid * kMaxNumMeshLODs;
     const float* lodError = a.cache.error + (uint64_t)cid * kMaxNumMeshLODs;
     uint32_t lod = 0;
     if (k.m_ForcedMeshLOD != kInvalidMeshLOD) {
@@ -211,7 +211,9 @@ __device__ __forceinline__ uint32_t classify(const InstanceCullArgs& a, uint32_t
             if (lodError[i] < threshold) lod = i;
     }
     lod = lod < kMaxNumMeshLODs ? lod : kMaxNumMeshLODs - 1u;                       // never index past the table
-    const uint32_t numMeshlets = lodMeshlets[lod];
+    const uint2 li = lodInfo[lod];                                                  // {m_NumMeshlets, m_MeshletDataBufferIdx}
+    *lodOut = li;
+    const uint32_t numMeshlets = li.x;
     const uint32_t groups = (numMeshlets + kNumThreadsPerWave - 1u) / kNumThreadsPerWave; // DivideAndRoundUp
     *tileOut = screenTile(cv, k.m_P00, k.m_P11);
     return kWordSubmit | (lod << 27) | (groups & kGroupMask);
@@ -229,10 +231,14 @@ __global__ __launch_bounds__(kBlock) void instanceClassifyKernel(InstanceCullArg
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 
     uint32_t word = 0, tile = 0;
-    if (t < n) word = classify<LATE>(a, a.ids[t], &tile);
+    uint2 lodSel = make_uint2(0u, 0u);
+    if (t < n) word = classify<LATE>(a, a.ids[t], &tile, &lodSel);
 
     const uint32_t g = (word & kWordSubmit) ? (word & kGroupMask) : 0u;
     if (g != 0 && n >= kMinBinnedEntries) {
+        a.lodSel[t] = lodSel;
+        // (Handing out the place inside the run here, from the value the update returns, and dropping the emit kernel's
+        // second round of atomics was tried: classify 39 -> 45 us, emit no faster.)
         atomicAdd(&a.tileCount[tile * a.tileReplicas + (blockIdx.x % a.tileReplicas)], g);   // histogram of groups per screen tile
         a.tileOf[t] = (uint16_t)tile;
     }
@@ -272,6 +278,38 @@ __global__ __launch_bounds__(1024) void instanceScanKernel(InstanceCullArgs a)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n = threadCount<LATE>(a);
     const uint32_t activeBlocks = (n + kBlock - 1) / kBlock < a.numBlocks ? (n + kBlock - 1) / kBlock : a.numBlocks;
+    // Two workgroups, two independent jobs: 0 scans the per-block sums and closes the counters, 1 turns the tile histogram
+    // into run starts.
+    if (blockIdx.x == 1) {
+        // tile histogram -> exclusive prefix (run starts for the emit kernel); thread = tile, its replicas are contiguous
+        if (n >= kMinBinnedEntries) {
+            __shared__ uint32_t s_w[16];
+            uint32_t rep[REPLICAS];
+            uint32_t c = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < REPLICAS; i += 4) {
+                const uint4 v = *reinterpret_cast<const uint4*>(&a.tileCount[tid * REPLICAS + i]);
+                rep[i] = v.x; rep[i + 1] = v.y; rep[i + 2] = v.z; rep[i + 3] = v.w;
+                c += v.x + v.y + v.z + v.w;
+            }
+            uint32_t inc = waveInclusiveScan(c, lane);
+            if (lane == 63) s_w[wave] = inc;
+            __syncthreads();
+            uint32_t pre = 0;
+            for (uint32_t w = 0; w < wave; ++w) pre += s_w[w];
+            uint32_t run = pre + inc - c;
+#pragma unroll
+            for (uint32_t i = 0; i < REPLICAS; i += 4) {
+                uint4 v;
+                v.x = run; run += rep[i];
+                v.y = run; run += rep[i + 1];
+                v.z = run; run += rep[i + 2];
+                v.w = run; run += rep[i + 3];
+                *reinterpret_cast<uint4*>(&a.tileCount[tid * REPLICAS + i]) = v;
+            }
+        }
+        return;
+    }
     uint32_t carryG = 0, flip = 0;
     uint64_t carryLS = 0;
     for (uint32_t base = 0; base < activeBlocks; base += 1024) {
@@ -328,35 +366,6 @@ __global__ __launch_bounds__(1024) void instanceScanKernel(InstanceCullArgs a)
         a.permHeader[0] = (n >= kMinBinnedEntries && baseX == 0 && X < a.maxGroups && X <= a.permCapacity) ? 1u : 0u;
         a.permHeader[1] = X;
     }
-    // tile histogram -> exclusive prefix (cursors for the emit kernel); thread = tile, its replicas are contiguous
-    if (n >= kMinBinnedEntries) {
-        __syncthreads();
-        const uint32_t lane = tid & 63u, wave = tid >> 6;
-        uint32_t rep[REPLICAS];
-        uint32_t c = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < REPLICAS; i += 4) {
-            const uint4 v = *reinterpret_cast<const uint4*>(&a.tileCount[tid * REPLICAS + i]);
-            rep[i] = v.x; rep[i + 1] = v.y; rep[i + 2] = v.z; rep[i + 3] = v.w;
-            c += v.x + v.y + v.z + v.w;
-        }
-        uint32_t inc = waveInclusiveScan(c, lane);
-        __shared__ uint32_t s_w[16];
-        if (lane == 63) s_w[wave] = inc;
-        __syncthreads();
-        uint32_t pre = 0;
-        for (uint32_t w = 0; w < wave; ++w) pre += s_w[w];
-        uint32_t run = pre + inc - c;
-#pragma unroll
-        for (uint32_t i = 0; i < REPLICAS; i += 4) {
-            uint4 v;
-            v.x = run; run += rep[i];
-            v.y = run; run += rep[i + 1];
-            v.z = run; run += rep[i + 2];
-            v.w = run; run += rep[i + 3];
-            *reinterpret_cast<uint4*>(&a.tileCount[tid * REPLICAS + i]) = v;
-        }
-    }
 }
 
 template <int LATE>
@@ -388,9 +397,8 @@ __global__ __launch_bounds__(kBlock) void instanceEmitKernel(InstanceCullArgs a)
         const uint32_t p = atomicAdd(&a.tileCount[(uint32_t)a.tileOf[t] * a.tileReplicas + (blockIdx.x % a.tileReplicas)], groups);
         // the record resolved through the LOD table here, once per instance (basepass.hlsl:54-63): the meshlet cull then
         // reads 16 bytes of this list and one 64-byte block of the instance cache per record, nothing else
-        const uint32_t cid = id < a.numInstances ? id : 0u;
-        const uint32_t numMeshlets = a.cache.numMeshlets[(uint64_t)cid * kMaxNumMeshLODs + lod];
-        const uint32_t base = a.cache.meshletBase[(uint64_t)cid * kMaxNumMeshLODs + lod];
+        const uint2 li = a.lodSel[t];
+        const uint32_t numMeshlets = li.x, base = li.y;
         for (uint32_t i = 0; i < groups; ++i) {
             const uint32_t first = i * kNumThreadsPerWave;
             const uint32_t cnt = numMeshlets > first ? (numMeshlets - first < kNumThreadsPerWave ? numMeshlets - first : kNumThreadsPerWave) : 0u;
@@ -433,7 +441,8 @@ __global__ __launch_bounds__(kBlock) void instanceFusedKernel(InstanceCullArgs a
         if (tile >= numTiles && !(tile == 0 && numTiles == 0)) return;
         const uint32_t t = tile * kBlock + tid;
         uint32_t word = 0, tileUnused = 0;
-        if (t < n) word = classify<LATE>(a, a.ids[t], &tileUnused);
+        uint2 lodUnused;
+        if (t < n) word = classify<LATE>(a, a.ids[t], &tileUnused, &lodUnused);
         const uint32_t g = (word & kWordSubmit) ? (word & kGroupMask) : 0u;
         const uint32_t late = word >> 31;
         const uint32_t submit = (word >> 30) & 1u;
@@ -626,7 +635,8 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
     a.tileReplicas = nMax >= (1u << 18) ? kTileReplicas : kTileReplicasSmall;
     a.tileCount = (uint32_t*)ctx.scratch(kNumTiles * a.tileReplicas * 4);
     a.tileOf = (uint16_t*)ctx.scratch((size_t)nMax * 2);
-    TRHIP_REQUIRE(a.word && a.localOff && a.blockGroups && a.blockLateSubmit && a.bases && a.tileCount && a.tileOf, "%s: scratch allocation failed", ctx.shaderName);
+    a.lodSel = (uint2*)ctx.scratch((size_t)nMax * 8);
+    TRHIP_REQUIRE(a.word && a.localOff && a.blockGroups && a.blockLateSubmit && a.bases && a.tileCount && a.tileOf && a.lodSel, "%s: scratch allocation failed", ctx.shaderName);
     // sidecar of the amplification buffer: header + one u32 per record slot
     {
         const uint64_t need = (uint64_t)kPermHeaderWords * 4 + (uint64_t)a.maxGroups * 16;
@@ -670,8 +680,8 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
         hipLaunchKernelGGL(instanceClassifyKernel<LATE>, dim3(a.numBlocks), dim3(kBlock), 0, s, a);
         return trhip::launchStatus("instanceClassifyKernel"); });
     ctx.emit("scan", [a](hipStream_t s) {
-        if (a.tileReplicas == kTileReplicas) hipLaunchKernelGGL((instanceScanKernel<LATE, kTileReplicas>), dim3(1), dim3(1024), 0, s, a);
-        else hipLaunchKernelGGL((instanceScanKernel<LATE, kTileReplicasSmall>), dim3(1), dim3(1024), 0, s, a);
+        if (a.tileReplicas == kTileReplicas) hipLaunchKernelGGL((instanceScanKernel<LATE, kTileReplicas>), dim3(2), dim3(1024), 0, s, a);
+        else hipLaunchKernelGGL((instanceScanKernel<LATE, kTileReplicasSmall>), dim3(2), dim3(1024), 0, s, a);
         return trhip::launchStatus("instanceScanKernel"); });
     const size_t scanOp = ctx.cl->ops.size() - 1;
     ctx.emit("emit", [a](hipStream_t s) {
@@ -705,8 +715,8 @@ int recordBuildLateArgs(trhip::DispatchCtx& ctx)
                     hipLaunchKernelGGL(instanceFusedKernel<0>, dim3(fused.numBlocks), dim3(kBlock), 0, s, fused);
                     return trhip::launchStatus("instanceFusedKernel"); };
             else ctx.cl->ops[scanOp].fn = [fused](hipStream_t s) {
-                if (fused.tileReplicas == kTileReplicas) hipLaunchKernelGGL((instanceScanKernel<0, kTileReplicas>), dim3(1), dim3(1024), 0, s, fused);
-                else hipLaunchKernelGGL((instanceScanKernel<0, kTileReplicasSmall>), dim3(1), dim3(1024), 0, s, fused);
+                if (fused.tileReplicas == kTileReplicas) hipLaunchKernelGGL((instanceScanKernel<0, kTileReplicas>), dim3(2), dim3(1024), 0, s, fused);
+                else hipLaunchKernelGGL((instanceScanKernel<0, kTileReplicasSmall>), dim3(2), dim3(1024), 0, s, fused);
                 return trhip::launchStatus("instanceScanKernel"); };
             // this dispatch's accesses (count read, arguments written) now happen in the scan command
             for (size_t i = ctx.cl->useMarks.size(); i-- > 0 && ctx.cl->useMarks[i].op >= ctx.cl->ops.size();) ctx.cl->useMarks[i].op = scanOp;
