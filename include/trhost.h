@@ -67,6 +67,14 @@ int  trhost_upload_hzb_mip(uint32_t mip, const uint16_t* texels, uint64_t bytes)
 int  trhost_download_hzb_mip(uint32_t mip, uint16_t* texels, uint64_t bytes);
 int  trhost_hzb_info(uint32_t* width, uint32_t* height, uint32_t* mips);
 
+/* GI debug view (GIDebugRenderer, GIRenderer.cpp:598-808): probe world positions (3 floats each) and states (1 float each,
+ * 1 = RTXGI_DDGI_PROBE_STATE_INACTIVE) as the DDGI volume would provide them; from then on every frame runs
+ * "giprobevisualization_CS_VisualizeGIProbesCulling" after the base pass.  num_probes = 0 switches it off.
+ * trhost_gi_probe_buffers: trhip_buffer handles of the last dispatch's outputs (positions, DrawIndexedIndirectArguments,
+ * instance -> probe index). */
+int  trhost_load_gi_probes(const float* positions, const float* states, uint32_t num_probes, float probe_radius, int hide_inactive);
+int  trhost_gi_probe_buffers(void** positions, void** draw_args, void** instance_to_probe);
+
 int  trhost_frame(void);       /* Graphic::Update: record every pass, submit, (asynchronous)       */
 int  trhost_wait_idle(void);
 

@@ -124,6 +124,8 @@ def lib() -> C.CDLL:
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                         C.c_void_p]
         L.orc_build_late_args.argtypes = [C.c_uint32, C.c_void_p]
+        L.orc_gi_probe_cull.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_gi_probe_cull.restype = C.c_uint32
         L.orc_meshlet_cull.restype = C.c_uint64
         L.orc_meshlet_cull.argtypes = [C.c_void_p] * 5 + [C.c_uint32, C.c_uint32] + [C.c_void_p] * 4
         L.orc_hzb_build.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
@@ -241,6 +243,22 @@ def instance_cull(consts: np.ndarray, late: bool, instances, ids, meshData, hzb:
                             C.addressof(s), _p(records), _p(dispatchArgs), _p(lateCount), _p(lateIds),
                             int(lateArgsX), int(maxGroups), C.addressof(valid))
     return int(valid.value)
+
+
+def gi_probe_cull(consts: np.ndarray, positions, states, hzb: HzbTexture, draw_args=None):
+    """CS_VisualizeGIProbesCulling (giprobevisualization.hlsl:16-69) with probe positions / states as inputs.
+    consts: interop.GIProbeVisualizationUpdateConsts[1].  Returns (positions[k,3], drawArgs[5], instanceToProbe[k])."""
+    pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    st = np.ascontiguousarray(states, np.float32)
+    n = int(consts["m_NumProbes"][0])
+    assert len(pos) >= n and len(st) >= n
+    args = np.zeros(5, np.uint32) if draw_args is None else np.ascontiguousarray(draw_args, np.uint32).copy()
+    base = int(args[1])
+    out_pos = np.zeros((base + n, 3), np.float32)
+    out_idx = np.zeros(base + n, np.uint32)
+    h = hzb.struct()
+    k = lib().orc_gi_probe_cull(_p(consts), _p(pos), _p(st), C.byref(h), _p(out_pos), _p(args), _p(out_idx))
+    return out_pos[base:base + k], args, out_idx[base:base + k]
 
 
 def build_late_args(count: int) -> np.ndarray:

@@ -512,6 +512,28 @@ void orc_instance_cull(const OrcGPUCullingPassConstants* k, int lateCull,
 }
 
 /* gpuculling.hlsl:182-195 (Q1: 64, not kNumThreadsPerWave) */
+/* giprobevisualization.hlsl:16-69 */
+uint32_t orc_gi_probe_cull(const OrcGIProbeVisualizationUpdateConsts* k, const float* probePositions, const float* probeStates,
+                           const OrcHZB* hzb, float* outPositions, uint32_t* drawArgs, uint32_t* outInstanceToProbe)
+{
+    uint32_t appended = 0;
+    for (uint32_t probeIndex = 0; probeIndex < k->m_NumProbes; ++probeIndex) {      /* :18-23 */
+        if (k->m_bHideInactiveProbes && probeStates[probeIndex] == 1.0f) continue;   /* :29-34, RTXGI_DDGI_PROBE_STATE_INACTIVE */
+        const float* wp = probePositions + 3u * probeIndex;                          /* :36-37 (input instead of the DDGI volume) */
+        float v[3];
+        orc_to_view(wp, &k->m_WorldToView, v);                                        /* :39-40 */
+        if (!orc_frustum_cull(v, k->m_ProbeRadius, k->m_Frustum)) continue;           /* :42-45 */
+        if (!orc_occlusion_cull(v, k->m_ProbeRadius, k->m_NearPlane, k->m_P00, k->m_P11, hzb)) continue;   /* :47-60 */
+        const uint32_t outInstanceIndex = drawArgs[1]++;                              /* :62-63 InterlockedAdd(m_InstanceCount, 1) */
+        outPositions[3u * outInstanceIndex + 0] = wp[0];                              /* :66 */
+        outPositions[3u * outInstanceIndex + 1] = wp[1];
+        outPositions[3u * outInstanceIndex + 2] = wp[2];
+        outInstanceToProbe[outInstanceIndex] = probeIndex;                            /* :67 */
+        ++appended;
+    }
+    return appended;
+}
+
 void orc_build_late_args(uint32_t lateCount, uint32_t out[3])
 {
     out[0] = div_round_up(lateCount, 64);

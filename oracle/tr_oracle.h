@@ -179,6 +179,28 @@ void orc_instance_cull(const OrcGPUCullingPassConstants* k, int lateCull,
 void orc_occlusion_footprints(const float* centres, const float* radii, uint32_t n, const OrcMatrix* worldToView,
                               float P00, float P11, uint32_t hzbW, uint32_t hzbH, uint32_t mips, int32_t* out);
 
+/* ShaderInterop.h:249-261 (124 B) */
+typedef struct {
+    uint32_t m_NumProbes;
+    float m_CameraOrigin[3];
+    float m_Frustum[4];
+    OrcMatrix m_WorldToView;
+    uint32_t m_HZBDimensions[2];
+    float m_P00, m_P11, m_NearPlane, m_ProbeRadius;
+    uint32_t m_bHideInactiveProbes;
+} OrcGIProbeVisualizationUpdateConsts;
+
+/* CS_VisualizeGIProbesCulling (giprobevisualization.hlsl:16-69), the second consumer of FrustumCull / OcclusionCull.
+ * The reference reads a probe's state and world position from the RTXGI-DDGI volume (:29-38, DDGILoadProbeState /
+ * DDGIGetProbeWorldPosition: SDK code in an empty submodule); here both are INPUT arrays (positions: 3 floats per
+ * probe, states: one float per probe, RTXGI_DDGI_PROBE_STATE_INACTIVE = 1).  Everything from :40 on is restated:
+ * view transform, z flip, frustum test, occlusion test, compaction -- in ascending probe order (the reference appends
+ * with InterlockedAdd, i.e. in no defined order).  drawArgs = DrawIndexedIndirectArguments (5 words): m_InstanceCount
+ * (word 1) is incremented per visible probe from its incoming value, which is also where the appended entries start.
+ * Returns the number of probes appended. */
+uint32_t orc_gi_probe_cull(const OrcGIProbeVisualizationUpdateConsts* k, const float* probePositions, const float* probeStates,
+                           const OrcHZB* hzb, float* outPositions, uint32_t* drawArgs, uint32_t* outInstanceToProbe);
+
 /* CS_BuildLateCullIndirectArgs (gpuculling.hlsl:182-195), Q1: divides by 64. */
 void orc_build_late_args(uint32_t lateCount, uint32_t out[3]);
 

@@ -14,7 +14,7 @@ if [ "$MODE" = build ]; then
     name=$1; defs=$2; shift 2
     mkdir -p $LIB/exp/$name
     /opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-function --offload-arch=gfx950 $defs -c $CS/k_basepass_as.hip -o $LIB/exp/$name/k_basepass_as.o
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $LIB/exp/$name/libtrhip.so $LIB/obj/trhip_core.o $LIB/obj/k_gpuculling.o $LIB/exp/$name/k_basepass_as.o $LIB/obj/k_hzb.o $LIB/obj/k_updateinstance.o $LIB/obj/k_raster.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $LIB/exp/$name/libtrhip.so $LIB/obj/trhip_core.o $LIB/obj/k_gpuculling.o $LIB/exp/$name/k_basepass_as.o $LIB/obj/k_hzb.o $LIB/obj/k_updateinstance.o $LIB/obj/k_raster.o $LIB/obj/k_giprobe.o
     rm $LIB/exp/$name/k_basepass_as.o
     echo built $name "($defs)"
   done

@@ -128,6 +128,33 @@ struct MeshletAmplificationData
     uint32_t m_MeshletGroupOffset;
 };
 
+// ShaderInterop.h:108-115
+struct DrawIndexedIndirectArguments
+{
+    uint32_t m_IndexCount;
+    uint32_t m_InstanceCount;
+    uint32_t m_StartIndexLocation;
+    int32_t  m_BaseVertexLocation;
+    uint32_t m_StartInstanceLocation;
+};
+static_assert(sizeof(DrawIndexedIndirectArguments) == 20, "DrawIndexedIndirectArguments");
+
+// ShaderInterop.h:249-261
+struct GIProbeVisualizationUpdateConsts
+{
+    uint32_t m_NumProbes;
+    float m_CameraOrigin[3];
+    Vector4 m_Frustum;
+    Matrix m_WorldToView;
+    Vector2U m_HZBDimensions;
+    float m_P00;
+    float m_P11;
+    float m_NearPlane;
+    float m_ProbeRadius;
+    uint32_t m_bHideInactiveProbes;
+};
+static_assert(sizeof(GIProbeVisualizationUpdateConsts) == 124 && offsetof(GIProbeVisualizationUpdateConsts, m_WorldToView) == 32, "GIProbeVisualizationUpdateConsts");
+
 // ShaderInterop.h:214-218
 struct MinMaxDownsampleConsts
 {

@@ -16,6 +16,7 @@
 
 extern IRenderer* g_UpdateInstanceConstsRenderer;
 extern IRenderer* g_GBufferRenderer;
+extern IRenderer* g_GIDebugRenderer;
 
 void View::Update()
 {
@@ -163,6 +164,24 @@ void Scene::LoadNodes(const void* nodes, uint32_t numNodes, const uint32_t* prim
     m_bUpdateInstanceTransforms = true;
 }
 
+void Scene::LoadGIProbes(const float* positions, const float* states, uint32_t numProbes, float probeRadius, bool hideInactive)
+{
+    nvrhi::DeviceHandle device = g_Graphic.m_NVRHIDevice;
+    m_GIProbePositionsBuffer = m_GIProbeStatesBuffer = nullptr;
+    m_NumGIProbes = numProbes;
+    m_GIProbeRadius = probeRadius;
+    m_bHideInactiveGIProbes = hideInactive;
+    m_bShowGIProbes = numProbes != 0;
+    if (!numProbes) return;
+    nvrhi::BufferDesc d;
+    d.byteSize = 12ull * numProbes; d.structStride = 12; d.debugName = "GI Probe World Positions";
+    m_GIProbePositionsBuffer = device->createBuffer(d);
+    nvrhi::throwIfFailed(trhip_buffer_upload(m_GIProbePositionsBuffer->native(), 0, positions, d.byteSize), "Scene::LoadGIProbes");
+    d.byteSize = 4ull * numProbes; d.structStride = 4; d.debugName = "GI Probe States";
+    m_GIProbeStatesBuffer = device->createBuffer(d);
+    nvrhi::throwIfFailed(trhip_buffer_upload(m_GIProbeStatesBuffer->native(), 0, states, d.byteSize), "Scene::LoadGIProbes");
+}
+
 void Scene::PostSceneLoad() {}
 
 void Scene::Update()
@@ -176,6 +195,7 @@ void Scene::Update()
         HOST_PROFILE_SCOPE("RenderGraph::AddRenderer x2 (Setup)");
         m_RenderGraph->AddRenderer(g_UpdateInstanceConstsRenderer);
         m_RenderGraph->AddRenderer(g_GBufferRenderer);
+        m_RenderGraph->AddRenderer(g_GIDebugRenderer);                        // :509 (after the base pass: it reads this frame's HZB)
     }
     { HOST_PROFILE_SCOPE("RenderGraph::Compile"); m_RenderGraph->Compile(); }                            // :515
     { HOST_PROFILE_SCOPE("Executor::corun (Render)"); m_Executor.corun(tf); }                            // :518
@@ -190,4 +210,6 @@ void Scene::Shutdown()
     m_NodeLocalTransformsBuffer = m_PrimitiveIDToNodeIDBuffer = nullptr;
     m_HZB = nullptr;
     m_SyntheticDepth = nullptr;
+    m_GIProbePositionsBuffer = m_GIProbeStatesBuffer = nullptr;
+    m_NumGIProbes = 0; m_bShowGIProbes = false;
 }

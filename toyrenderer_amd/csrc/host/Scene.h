@@ -88,6 +88,15 @@ public:
     void LoadGeometry(const void* vertices, uint64_t numVertices, const uint32_t* meshletVertexIds, uint64_t numVertexIds,
                       const uint32_t* meshletTriangles, uint64_t numTriangles);
 
+    // GI debug view (GIRenderer.cpp:598-808): the probes' world positions and states as the DDGI volume would give them
+    // (inputs here: the RTXGI SDK is absent), culled every frame by GIDebugRenderer when m_bShowGIProbes is set.
+    void LoadGIProbes(const float* positions, const float* states, uint32_t numProbes, float probeRadius, bool hideInactive);
+    nvrhi::BufferHandle m_GIProbePositionsBuffer, m_GIProbeStatesBuffer;
+    uint32_t m_NumGIProbes = 0;
+    float m_GIProbeRadius = 0.1f;
+    bool m_bHideInactiveGIProbes = false, m_bShowGIProbes = false;
+    uint32_t m_GIProbeSphereIndexCount = 2880;       // index count of CommonResources' unit sphere mesh (draw side, out of scope)
+
     std::shared_ptr<RenderGraph> m_RenderGraph;
     tf::Executor m_Executor{ 4 };                    // Engine.cpp:19,110-116 (default 12 workers)
 };

@@ -29,6 +29,10 @@ using ShardLateFn = void (*)(void* user, void* hipStream, void* lateCount, void*
 using ShardDepthFn = int (*)(void* user, void* depthWords, uint64_t countWords, void* hipStream);
 void SetShardLateExchange(ShardLateFn fn, void* user, uint32_t listPresenceMask = 0, ShardDepthFn depthFn = nullptr, void* depthUser = nullptr);
 
+// Outputs of the last GI probe culling dispatch (GIRenderer.cpp; false before the first one).
+bool GetGIProbeCullBuffers(nvrhi::BufferHandle* positions, nvrhi::BufferHandle* drawArgs, nvrhi::BufferHandle* instanceToProbe);
+void ReleaseGIProbeCullBuffers();
+
 // Depth attachment of the last recorded base pass (read-back for tests; null before the first frame).
 nvrhi::TextureHandle GetLastDepthBuffer();
 

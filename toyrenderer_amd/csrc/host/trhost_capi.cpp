@@ -55,6 +55,7 @@ void trhost_shutdown(void)
     (void)guarded([&] {
         ShardExchangeDestroy();
         ReleaseVisibilityPassBuffers();
+        ReleaseGIProbeCullBuffers();
         g_Graphic.Shutdown();
     });
     s_Initialized = false;
@@ -218,6 +219,24 @@ int trhost_pass_buffers(uint32_t slot, trhost_pass_buffers_t* out)
 int trhost_instance_buffer(void** buffer)
 {
     return guarded([&] { *buffer = g_Scene->m_InstanceConstsBuffer ? (void*)g_Scene->m_InstanceConstsBuffer->native() : nullptr; });
+}
+
+int trhost_load_gi_probes(const float* positions, const float* states, uint32_t num_probes, float probe_radius, int hide_inactive)
+{
+    return guarded([&] {
+        check(num_probes == 0 || (positions && states));
+        g_Scene->LoadGIProbes(positions, states, num_probes, probe_radius, hide_inactive != 0);
+    });
+}
+
+int trhost_gi_probe_buffers(void** positions, void** draw_args, void** instance_to_probe)
+{
+    return guarded([&] {
+        check(positions && draw_args && instance_to_probe);
+        nvrhi::BufferHandle p, a, i;
+        if (!GetGIProbeCullBuffers(&p, &a, &i)) throw nvrhi::Error("no GI probe culling dispatch has been recorded");
+        *positions = p->native(); *draw_args = a->native(); *instance_to_probe = i->native();
+    });
 }
 
 int trhost_scene_list_sizes(uint32_t* num_opaque, uint32_t* num_alpha_mask)

@@ -22,7 +22,7 @@ HOST_SYMBOLS = [
     "trhost_heap_sim", "trhost_set_shard_late_exchange", "trhost_set_gpu_timers",
     "trhost_rccl_allgather", "trhost_exchange_create", "trhost_exchange_run", "trhost_exchange_wait", "trhost_exchange_outputs",
     "trhost_exchange_destroy", "trhost_load_geometry", "trhost_set_raster_depth", "trhost_download_depth",
-    "trhost_load_scene_cached", "trhost_scene_list_sizes", "trhost_rccl_allreduce_max_u32",
+    "trhost_load_scene_cached", "trhost_scene_list_sizes", "trhost_rccl_allreduce_max_u32", "trhost_load_gi_probes", "trhost_gi_probe_buffers",
 ]
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)   # trhost_allgather_fn
@@ -86,6 +86,8 @@ def load() -> C.CDLL:
     L.trhost_set_gpu_timers.argtypes = [C.c_int]
     L.trhost_exchange_create.argtypes = [C.POINTER(ExchangeDesc)]
     L.trhost_scene_list_sizes.argtypes = [C.POINTER(u32), C.POINTER(u32)]
+    L.trhost_load_gi_probes.argtypes = [vp, vp, u32, C.c_float, C.c_int]
+    L.trhost_gi_probe_buffers.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.trhost_exchange_outputs.argtypes = [u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.trhost_set_shard_late_exchange.argtypes = [SHARD_LATE_FN, vp]
     L.trhost_heap_sim.argtypes = [u64, vp, u32, vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
@@ -184,6 +186,21 @@ class Renderer:
         v = np.ascontiguousarray(vertices, I.RawVertexFormat)
         vid, tri = np.ascontiguousarray(meshlet_vertex_ids, np.uint32), np.ascontiguousarray(meshlet_triangles, np.uint32)
         _check(load().trhost_load_geometry(v.ctypes.data, len(v), vid.ctypes.data, len(vid), tri.ctypes.data, len(tri)))
+
+    def load_gi_probes(self, positions, states, radius: float, hide_inactive: bool = False):
+        """GI debug view: probe world positions [n,3] and states [n] (1 = inactive); GIDebugRenderer culls them every frame."""
+        p = np.ascontiguousarray(positions, np.float32).reshape(-1, 3); st = np.ascontiguousarray(states, np.float32)
+        assert len(p) == len(st)
+        _check(load().trhost_load_gi_probes(p.ctypes.data if len(p) else None, st.ctypes.data if len(st) else None, len(p), float(radius), int(hide_inactive)))
+
+    def gi_probe_results(self):
+        """(positions[k,3], DrawIndexedIndirectArguments (5 words), instance -> probe index [k]) of the last frame."""
+        self.wait_idle()
+        h = [C.c_void_p() for _ in range(3)]
+        _check(load().trhost_gi_probe_buffers(*[C.byref(x) for x in h]))
+        args = _download(h[1].value, np.uint32, 5)
+        k = int(args[1])
+        return _download(h[0].value, np.float32, 3 * k).reshape(-1, 3), args, _download(h[2].value, np.uint32, k)
 
     def set_raster_depth(self, on: bool = True):
         """The frame rasterises the depth of its own visible meshlets instead of taking the uploaded depth image."""

@@ -44,6 +44,12 @@ BasePassConstants = np.dtype([
     ("m_OutputResolution", np.uint32, (2,)), ("m_bVisualizeMinMipTilesOnAlbedoOutput", np.uint32),
     ("m_bWriteSamplerFeedback", np.uint32)])
 MinMaxDownsampleConsts = np.dtype([("m_OutputDimensions", np.uint32, (2,)), ("m_bDownsampleMax", np.uint32)])
+DrawIndexedIndirectArguments = np.dtype([("m_IndexCount", np.uint32), ("m_InstanceCount", np.uint32), ("m_StartIndexLocation", np.uint32),
+                                         ("m_BaseVertexLocation", np.int32), ("m_StartInstanceLocation", np.uint32)])     # ShaderInterop.h:108-115
+GIProbeVisualizationUpdateConsts = np.dtype([                                                                              # ShaderInterop.h:249-261
+    ("m_NumProbes", np.uint32), ("m_CameraOrigin", np.float32, (3,)), ("m_Frustum", np.float32, (4,)), ("m_WorldToView", np.float32, (4, 4)),
+    ("m_HZBDimensions", np.uint32, (2,)), ("m_P00", np.float32), ("m_P11", np.float32), ("m_NearPlane", np.float32), ("m_ProbeRadius", np.float32),
+    ("m_bHideInactiveProbes", np.uint32)])
 NodeLocalTransform = np.dtype([
     ("m_ParentNodeIdx", np.uint32), ("m_Position", np.float32, (3,)), ("m_Rotation", np.float32, (4,)),
     ("m_Scale", np.float32, (3,)), ("PAD0", np.uint32)])
