@@ -111,7 +111,8 @@ def test_loader_invariants_on_a_generated_file(tmp_path, oracle):
     assert s.primToNode.tolist() == [0, 1] and int(s.nodes[1]["m_ParentNodeIdx"]) == 0 and int(s.nodes[0]["m_ParentNodeIdx"]) == 0xFFFFFFFF
     md = s.meshData[0]
     n0 = int(md["m_MeshLODDatas"]["m_NumMeshlets"][0])
-    assert int(md["m_NumLODs"]) == 1 and n0 >= 3 and int(s.meshData[1]["m_MeshLODDatas"]["m_NumMeshlets"][0]) == 1
+    assert 2 <= int(md["m_NumLODs"]) <= 8 and n0 >= 3 and int(s.meshData[1]["m_MeshLODDatas"]["m_NumMeshlets"][0]) == 1
+    assert int(s.meshData[1]["m_NumLODs"]) == 1, "a single triangle pair cannot be simplified: one LOD (Visual.cpp:475-479)"
     covered = []
     for m in s.meshlets[:n0]:
         nv, nt = int(m["m_VertexAndTriangleCount"]) & 0xFF, int(m["m_VertexAndTriangleCount"]) >> 8
@@ -142,5 +143,79 @@ def test_loader_invariants_on_a_generated_file(tmp_path, oracle):
     view = gltf_lite.view_of(cam, (1200, 800))
     inst, ref = _cull(oracle, s, view, 5)
     assert np.allclose(inst["m_WorldMatrix"][1][3][:3], [np.sqrt(2.0), 0.0, -10 - np.sqrt(2.0)], atol=1e-5), "child = parent TRS applied to (1,0,0)"
-    assert ref.passRan[0] and ref.passRan[2] and int(ref.dispatchArgs[0][0]) == (n0 + 31) // 32 and int(ref.dispatchArgs[2][0]) == 1
-    assert 0 < int(ref.drawArgs[0][0]) <= n0
+    lod = int(ref.records[0].view(I.MeshletAmplificationData)["m_MeshLOD"][0])     # the LOD the oracle selected for the grid at this distance
+    n_lod = int(md["m_MeshLODDatas"]["m_NumMeshlets"][lod])
+    assert ref.passRan[0] and ref.passRan[2] and int(ref.dispatchArgs[0][0]) == (n_lod + 31) // 32 and int(ref.dispatchArgs[2][0]) == 1
+    assert 0 < int(ref.drawArgs[0][0]) <= n_lod
+
+
+def test_lod_chain_contract(tmp_path):
+    """Mesh::Initialize's LOD loop (Visual.cpp:326-491) with this build's own simplifier: <= 8 LODs, every LOD at most 85 %
+    of the previous one's indices, m_Error starts at 0 and never decreases (each step at least 1.5x the previous error,
+    :488), every LOD's meshlets partition exactly that LOD's triangles, uses only the mesh's own vertices and stays
+    within the relative error bound 0.1 of the original surface (measured: vertices of LOD 0 against the LOD's
+    triangles' planes is not needed -- a collapse keeps a subset of the vertices, so the bound is on the moved ones)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from scene_gen import _grid, _sphere
+    for pos, idx in (_sphere(16, 10), _grid(24, 0.05), _grid(2, 0.0)):
+        idx = idx.astype(np.uint32)
+        chain = gltf_lite.build_lod_chain(pos, idx)
+        assert 1 <= len(chain) <= 8 and np.array_equal(chain[0][0], idx) and chain[0][1] == 0.0
+        scale = gltf_lite.simplify_scale(pos)
+        for k in range(1, len(chain)):
+            (pi, pe), (ci, ce) = chain[k - 1], chain[k]
+            assert len(ci) % 3 == 0 and 0 < len(ci) < int(len(pi) * 0.85), "kMinIndexReductionPercentage"
+            assert len(ci) > (int(len(pi) * 0.65) // 3) * 3 - 6, "stops as soon as the target index count is reached (a collapse removes two triangles)"
+            assert ce >= pe * 1.5 - 1e-7 and ce > 0 and ce <= 0.1 * scale * 1.5 ** 8
+            assert ci.max() < len(pos) and set(np.unique(ci)) <= set(np.unique(idx)), "a LOD draws a subset of the mesh's vertices"
+            t = ci.reshape(-1, 3)
+            assert np.all((t[:, 0] != t[:, 1]) & (t[:, 1] != t[:, 2]) & (t[:, 0] != t[:, 2])), "no degenerate triangles"
+        if len(idx) == 6:
+            assert len(chain) == 1
+        else:
+            assert len(chain) >= 3
+    # the simplifier alone: stops at the error bound when asked for more than the bound allows
+    pos, idx = _sphere(16, 10)
+    few, err = gltf_lite.simplify(pos, idx.astype(np.uint32), 30, 0.01)
+    assert err <= 0.01 and len(few) > 30
+    same, err0 = gltf_lite.simplify(pos, idx.astype(np.uint32), len(idx), 0.1)
+    assert np.array_equal(same, idx.astype(np.uint32)) and err0 == 0.0
+
+
+def test_loaded_scene_carries_the_lod_chain(tmp_path, oracle):
+    """Generated city scene: the LODs land in MeshData (ranges, errors) and in the meshlet / geometry buffers; every LOD's
+    meshlets cover exactly its triangles; the oracle's LOD selection (gpuculling.hlsl:39-57) picks coarser LODs for the
+    far spheres than for the near ones."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from scene_gen import write_city_gltf
+    s = gltf_lite.load(write_city_gltf(tmp_path))
+    sphere = s.meshData[1]
+    nl = int(sphere["m_NumLODs"])
+    assert nl >= 3
+    lods = sphere["m_MeshLODDatas"]
+    errs = lods["m_Error"][:nl]
+    assert errs[0] == 0 and np.all(np.diff(errs) > 0)
+    counts = lods["m_NumMeshlets"][:nl].astype(np.int64)
+    bases = lods["m_MeshletDataBufferIdx"][:nl].astype(np.int64)
+    assert np.all(np.diff(bases) == counts[:-1]), "LOD meshlet ranges are consecutive (Visual.cpp:344)"
+    assert counts[-1] < counts[0]
+    tri_counts = []
+    for k in range(nl):
+        n_t = 0
+        for m in s.meshlets[bases[k]:bases[k] + counts[k]]:
+            nv, nt = int(m["m_VertexAndTriangleCount"]) & 0xFF, int(m["m_VertexAndTriangleCount"]) >> 8
+            packed = s.meshletTriangles[int(m["m_MeshletIndexIDsBufferIdx"]):][:nt]
+            assert max((packed & 0xFF).max(), ((packed >> 8) & 0xFF).max(), ((packed >> 16) & 0xFF).max()) < nv
+            n_t += nt
+        tri_counts.append(n_t)
+    assert all(b < a * 0.85 for a, b in zip(tri_counts, tri_counts[1:]))
+    view = gltf_lite.view_of(s.cameras[0], (1280, 720))
+    inst, ref = _cull(oracle, s, view, 1)
+    rec = ref.records[0].view(I.MeshletAmplificationData)
+    sphere_rec = rec[s.instances["m_MeshDataIdx"][rec["m_InstanceConstIdx"]] == 1]
+    assert len(np.unique(sphere_rec["m_MeshLOD"])) >= 2, "near and far spheres use different LODs"
+    z = -inst["m_WorldMatrix"][sphere_rec["m_InstanceConstIdx"], 3, 2]
+    near, far = sphere_rec["m_MeshLOD"][z < np.percentile(z, 25)], sphere_rec["m_MeshLOD"][z > np.percentile(z, 75)]
+    assert far.mean() > near.mean()

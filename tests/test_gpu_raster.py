@@ -177,6 +177,8 @@ def test_drop_in_path_renders_its_own_depth(oracle, tmp_path):
             geo = (I.world_to_clip(V, P), s.vertices, s.meshletVertexIds, s.meshletTriangles)
             ref = oracle.frame(sc, view.as_dict(), hzb, depth, cullingFlags=7, record_capacity=4096, maxGroups=4096, raster=geo)
             _compare_frame(got, ref)
+            if f == 0:   # the ingested scene carries its own LOD chain (gltf_lite.build_lod_chain): LOD selection picks from it
+                assert len(np.unique(got[0]["records"]["m_MeshLOD"])) >= 2 and int(s.meshData["m_NumLODs"].max()) >= 3
             assert np.array_equal(r.download_depth().view(np.uint32), depth.view(np.uint32)), f"frame {f}: depth differs"
             assert np.array_equal(r.download_hzb(), hzb.texels), f"frame {f}: HZB chain differs"
         assert np.count_nonzero(depth) > 0.2 * depth.size

@@ -87,8 +87,8 @@ def test_winding_and_draw_order_do_not_matter_and_near_crossing_triangles_are_dr
     assert np.all(d4 == np.float32(0.9))
 
 
-def _load_city(tmp_path, oracle):
-    s = gltf_lite.load(write_city_gltf(tmp_path))
+def _load_city(tmp_path, oracle, lods=True):
+    s = gltf_lite.load(write_city_gltf(tmp_path), lods=lods)
     inst = s.instances.copy()
     oracle.update_instance_consts(s.nodes, s.primToNode, inst)
     sc = dict(s.as_oracle()); sc["instances"] = inst
@@ -113,7 +113,10 @@ def test_two_phase_frames_on_own_depth_lose_no_pixel(tmp_path, oracle):
     everything the frustum + cone tests keep.  The HZB test is conservative up to fp16 rounding of the pyramid (the HZB
     stores min depth rounded to NEAREST, Q10), so a handful of pixels may differ; the bound below is a property of the
     reference's algorithm, not of this restatement."""
-    s, sc = _load_city(tmp_path, oracle)
+    # LOD 0 only: with a LOD chain the early pass selects the LOD from the PREVIOUS frame's view position when occlusion
+    # culling is on (Q3), so a moving camera draws other LODs than the occlusion-free comparison frame -- a different
+    # property from the one measured here
+    s, sc = _load_city(tmp_path, oracle, lods=False)
     cam = s.cameras[0]
     render = (640, 360)
     P = synth.perspective_rh_reverse_z_infinite(cam.yfov, render[0] / render[1], cam.znear)

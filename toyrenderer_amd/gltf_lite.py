@@ -6,8 +6,10 @@ therefore THIS build's own (restating the published algorithms), not bit-compara
 kept verbatim is everything the cull path depends on: the limits (64 vertices / 96 triangles per meshlet,
 ShaderInterop.h:19-20), the wire formats, the cone packing (Visual.cpp:421-431: axis (a+1)/2*255 truncated, cutoff =
 2 * cone_cutoff_s8), one `Primitive` per glTF primitive of every mesh node (SceneLoading.cpp:853-862), world matrices
-through the node-transform pass, opaque / alpha-mask id lists.  LOD 0 only (the reference's other LODs come from
-meshopt_simplify).
+through the node-transform pass, opaque / alpha-mask id lists, and the LOD chain CONTRACT of Mesh::Initialize
+(Visual.cpp:326-491: up to 8 LODs, each simplified from the previous one towards 65 % of its indices under a relative
+error bound of 0.1, the stop rules, the error accumulation `max(1.5 * previous, result)` scaled by the mesh extent) --
+with this build's own edge-collapse simplifier (`simplify`) in the place of meshopt_simplifyWithAttributes.
 
 Supported: .gltf + external .bin (or a dict + bytes), float32 POSITION, u8/u16/u32 indices or none, node TRS or
 matrix-free hierarchies, perspective cameras, alphaMode MASK.
@@ -165,8 +167,193 @@ def build_meshlets(indices: np.ndarray):
     return out
 
 
+# ----------------------------------------------------------------------------------------------- LOD chain
+def simplify_scale(positions: np.ndarray) -> float:
+    """meshopt_simplifyScale (Visual.cpp:324): the factor between relative and absolute error = the largest extent of the
+    bounding box."""
+    p = np.asarray(positions, np.float64).reshape(-1, 3)
+    return float((p.max(0) - p.min(0)).max()) if len(p) else 0.0
+
+
+def simplify(positions: np.ndarray, indices: np.ndarray, target_index_count: int, target_error: float):
+    """Edge-collapse simplification in the role of meshopt_simplifyWithAttributes(options = 0) at Visual.cpp:456-471: the
+    result uses a SUBSET of the input vertices (a collapse moves one end of an edge onto the other), stops at
+    `target_index_count` indices or when the cheapest remaining collapse would exceed `target_error` (relative to
+    simplify_scale), never flips a triangle and never moves a boundary vertex off its boundary.  Cost of a collapse = the
+    quadric error (area-weighted squared distance to the planes around the moved vertex, Garland-Heckbert) as an RMS
+    distance.  Returns (indices uint32, result_error relative).  Own algorithm: same contract, other triangles than
+    meshoptimizer would pick."""
+    import heapq
+    P = np.asarray(positions, np.float64).reshape(-1, 3)
+    if len(indices) <= target_index_count:
+        return np.asarray(indices, np.uint32).copy(), 0.0
+    tris = [tuple(int(x) for x in t) for t in np.asarray(indices, np.int64).reshape(-1, 3)]
+    tris = [t for t in tris if len(set(t)) == 3]
+    scale = simplify_scale(P[np.unique(np.array(tris).ravel())]) if tris else 0.0
+    if not tris or scale == 0.0:
+        return np.asarray(indices, np.uint32).copy(), 0.0
+    limit = (target_error * scale) ** 2
+    # weld by position: collapses work on position classes so that attribute seams (duplicated positions) stay closed
+    _, remap = np.unique(np.round(P / (scale * 1e-7)).astype(np.int64), axis=0, return_inverse=True)
+    remap = remap.ravel()
+    Q = {}                                             # class -> [4x4 quadric, weight]
+    vt = {}                                            # class -> set of triangle ids
+    alive = {}
+    tri_cls = []
+
+    def plane_quadric(a, b, c):
+        n = np.cross(b - a, c - a)
+        area = float(np.linalg.norm(n))
+        if area == 0.0:
+            return None, 0.0
+        n = n / area
+        pl = np.append(n, -float(n @ a))
+        return np.outer(pl, pl) * area, area
+
+    for ti, t in enumerate(tris):
+        c = tuple(int(remap[v]) for v in t)
+        tri_cls.append(c)
+        if len(set(c)) < 3:
+            continue
+        alive[ti] = True
+        q, w = plane_quadric(P[t[0]], P[t[1]], P[t[2]])
+        for v in c:
+            vt.setdefault(v, set()).add(ti)
+            if q is not None:
+                e = Q.setdefault(v, [np.zeros((4, 4)), 0.0])
+                e[0] += q; e[1] += w
+    rep = {}                                           # class -> a representative input vertex (position)
+    for v, c in enumerate(remap):
+        rep.setdefault(int(c), v)
+    # boundary edges (one adjacent triangle) get a perpendicular plane so that borders keep their shape
+    edge_count = {}
+    for ti in alive:
+        c = tri_cls[ti]
+        for i in range(3):
+            e = (min(c[i], c[(i + 1) % 3]), max(c[i], c[(i + 1) % 3]))
+            edge_count.setdefault(e, []).append(ti)
+    border = set()
+    for (a, b), ts in edge_count.items():
+        if len(ts) == 1:
+            border.update((a, b))
+            c = tri_cls[ts[0]]
+            pa, pb = P[rep[a]], P[rep[b]]
+            other = P[rep[[x for x in c if x not in (a, b)][0]]]
+            n = np.cross(pb - pa, other - pa)
+            d = np.cross(n, pb - pa)
+            ld = float(np.linalg.norm(d))
+            if ld > 0:
+                d /= ld
+                w = float(np.linalg.norm(pb - pa)) ** 2 * 10.0
+                pl = np.append(d, -float(d @ pa))
+                for v in (a, b):
+                    e = Q.setdefault(v, [np.zeros((4, 4)), 0.0])
+                    e[0] += np.outer(pl, pl) * w; e[1] += w
+    version = {v: 0 for v in vt}
+
+    def cost(u, v):                                    # move class u onto class v
+        q, w = Q.get(u, (None, 0.0))
+        if q is None or w <= 0.0:
+            return 0.0
+        x = np.append(P[rep[v]], 1.0)
+        return max(float(x @ q @ x) / w, 0.0)
+
+    heap = []
+
+    def push(u):
+        nbrs = set()
+        for ti in vt.get(u, ()):
+            nbrs.update(tri_cls[ti])
+        nbrs.discard(u)
+        for v in nbrs:
+            if u in border and v not in border:
+                continue                               # a boundary vertex only slides along the boundary
+            heapq.heappush(heap, (cost(u, v), u, v, version[u], version[v]))
+    for u in list(vt):
+        push(u)
+    n_idx = 3 * len(alive)
+    worst = 0.0
+    while heap and n_idx > target_index_count:
+        c_, u, v, vu, vv = heapq.heappop(heap)
+        if u not in version or v not in version or version[u] != vu or version[v] != vv:
+            continue
+        if c_ > limit:
+            break
+        # reject collapses that flip or degenerate a surviving triangle
+        ok = True
+        for ti in vt[u]:
+            c = tri_cls[ti]
+            if v in c:
+                continue                               # disappears
+            a, b, d = (P[rep[x]] for x in c)
+            n0 = np.cross(b - a, d - a)
+            a2, b2, d2 = (P[rep[v if x == u else x]] for x in c)
+            n1 = np.cross(b2 - a2, d2 - a2)
+            if float(n0 @ n1) <= 1e-12 * float(n0 @ n0):
+                ok = False
+                break
+        if not ok:
+            continue
+        worst = max(worst, c_)
+        touched = set()
+        for ti in list(vt[u]):
+            c = tri_cls[ti]
+            if v in c:                                  # collapses to a line
+                for x in c:
+                    vt[x].discard(ti)
+                    touched.add(x)
+                del alive[ti]
+                n_idx -= 3
+            else:
+                nc = tuple(v if x == u else x for x in c)
+                tri_cls[ti] = nc
+                vt[v].add(ti)
+                touched.update(nc)
+        Q.setdefault(v, [np.zeros((4, 4)), 0.0])
+        if u in Q:
+            Q[v][0] += Q[u][0]; Q[v][1] += Q[u][1]
+        if u in border:
+            border.add(v)
+        del vt[u]; del version[u]
+        touched.discard(u)
+        for x in touched:
+            if x in version:
+                version[x] += 1
+        for x in touched:
+            if x in version:
+                push(x)
+    # a class is drawn with its representative vertex; keep the input triangle order
+    out = []
+    for ti in sorted(alive):
+        out.extend(rep[x] for x in tri_cls[ti])
+    return np.array(out, np.uint32), math.sqrt(worst) / scale
+
+
+def build_lod_chain(positions: np.ndarray, indices: np.ndarray, simplifier=simplify):
+    """The LOD loop of Mesh::Initialize (Visual.cpp:326-491): returns [(indices, error)] for LOD 0..n-1, n <= 8, with
+    error = accumulated relative error * simplify_scale (the value MeshLODData::m_Error carries, :345)."""
+    kTargetError, kTargetIndexCountPercentage, kMinIndexReductionPercentage = 0.1, 0.65, 0.85      # :336-338
+    scale = np.float32(simplify_scale(positions))                                                 # :324
+    lod_indices = np.asarray(indices, np.uint32).copy()
+    lod_error = np.float32(0.0)
+    out = []
+    for _ in range(I.kMaxNumMeshLODs):                                                            # :329
+        out.append((lod_indices, float(np.float32(lod_error * scale))))                           # :343-345
+        target = (int(float(len(lod_indices)) * kTargetIndexCountPercentage) // 3) * 3            # :454
+        simplified, result_error = simplifier(positions, lod_indices, target, kTargetError)      # :455-471
+        assert len(simplified) <= len(lod_indices)
+        if len(simplified) == len(lod_indices) or len(simplified) == 0:                           # :475-479 error bound reached
+            break
+        if len(simplified) >= int(float(len(lod_indices)) * kMinIndexReductionPercentage):        # :481-485 too close to the last one
+            break
+        lod_indices = simplified                                                                  # :487
+        lod_error = max(np.float32(lod_error * np.float32(1.5)), np.float32(result_error))        # :488 errors accumulate
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- loader
-def load(path_or_gltf, blobs=None) -> LoadedScene:
+def load(path_or_gltf, blobs=None, lods: bool = True) -> LoadedScene:
+    """lods=False: LOD 0 only (no simplification)."""
     if isinstance(path_or_gltf, dict):
         g = path_or_gltf
         blobs = list(blobs or [])
@@ -194,11 +381,16 @@ def load(path_or_gltf, blobs=None) -> LoadedScene:
             idx = idx[:len(idx) // 3 * 3]
             row = np.zeros((), I.MeshData)
             row["m_BoundingSphere"] = bounding_sphere(pos)              # Visual.cpp:321
-            row["m_NumLODs"] = 1
             row["m_GlobalVertexBufferIdx"] = vertex_base
-            row["m_MeshLODDatas"]["m_MeshletDataBufferIdx"][0] = len(ml_rows)
-            meshlets = build_meshlets(idx)
-            row["m_MeshLODDatas"]["m_NumMeshlets"][0] = len(meshlets)
+            chain = build_lod_chain(pos, idx) if lods else [(idx, 0.0)]
+            row["m_NumLODs"] = len(chain)
+            meshlets = []
+            for lod, (lod_idx, lod_err) in enumerate(chain):                             # Visual.cpp:341-431 per LOD
+                lod_meshlets = build_meshlets(lod_idx)
+                row["m_MeshLODDatas"]["m_MeshletDataBufferIdx"][lod] = len(ml_rows) + len(meshlets)
+                row["m_MeshLODDatas"]["m_NumMeshlets"][lod] = len(lod_meshlets)
+                row["m_MeshLODDatas"]["m_Error"][lod] = lod_err
+                meshlets.extend(lod_meshlets)
             for vids, tri in meshlets:
                 m = np.zeros((), I.MeshletData)
                 m["m_BoundingSphere"] = bounding_sphere(pos[vids])
