@@ -68,6 +68,10 @@ int  trhip_device_create(int device_index, trhip_device* out);
 int  trhip_device_create_on_stream(int device_index, void* hip_stream, trhip_device* out);
 void trhip_device_destroy(trhip_device dev);
 int  trhip_device_wait_idle(trhip_device dev);                 /* nvrhi waitForIdle, Graphic.cpp:790 */
+/* Orders the device's stream after everything its lists have put on the back end's internal side stream so far: an event
+ * recorded on trhip_device_stream() afterwards covers ALL work of the lists executed before (what another queue waits
+ * for: nvrhi queueWaitForCommandList). */
+int  trhip_device_join_side_stream(trhip_device dev);
 int  trhip_device_info(trhip_device dev, uint32_t* compute_units, uint32_t* wave_size, uint64_t* total_mem);
 void* trhip_device_stream(trhip_device dev);                   /* the hipStream_t in use            */
 

@@ -145,6 +145,13 @@ int  trhost_exchange_wait(void);
 int  trhost_exchange_outputs(uint32_t pass_slot, void** records, void** masks, void** list, void** args);
 int  trhost_exchange_destroy(void);
 
+/* Async compute (RenderGraph.cpp:251 "TODO: compute queue" in the reference): which queue a renderer records for --
+ * 0 graphics (default), 1 compute = a second stream; the render graph derives the cross-queue waits from the passes'
+ * declared resource accesses.  renderer_name: "UpdateInstanceConstsRenderer", "GBufferRenderer", "GIDebugRenderer". */
+int  trhost_set_renderer_queue(const char* renderer_name, int queue);
+/* Of the last frame: passes on the compute queue, cross-queue waits placed, bytes of live transient resources and what
+ * an allocator that aliases non-overlapping pass lifetimes would need for them. */
+int  trhost_render_graph_frame_stats(uint32_t* compute_queue_passes, uint32_t* cross_queue_waits, uint64_t* transient_bytes, uint64_t* aliased_bytes);
 int  trhost_render_graph_stats(uint32_t* num_heaps, uint64_t* bytes_reserved, uint64_t* bytes_used, uint32_t* num_passes);
 /* renderer_name "<frame>": host milliseconds the last trhost_frame spent recording (cpu_ms) and submitting (gpu_ms). */
 int  trhost_renderer_times(const char* renderer_name, float* cpu_ms, float* gpu_ms);

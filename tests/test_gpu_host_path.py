@@ -86,9 +86,11 @@ def test_group_cap_q2_through_host(oracle):
         assert ref.dispatchArgs[0][0] > 257 > ref.validRecords[0]
 
 
-def test_animated_transforms_then_cull(oracle):
+@pytest.mark.parametrize("async_compute", [False, True])
+def test_animated_transforms_then_cull(oracle, async_compute):
     """configs[4] in miniature: UpdateInstanceConstsRenderer rewrites the world matrices on the GPU every
-    frame from the node hierarchy, then the cull runs on them."""
+    frame from the node hierarchy, then the cull runs on them.  async_compute: the update pass records for the compute
+    queue; the base pass (graphics queue) reads the instance buffer it writes, so the graph makes it wait."""
     rng = np.random.default_rng(3)
     view = synth.make_view(render=(640, 360))
     spec = synth.SceneSpec(num_meshes=12, num_instances=200, meshlets_lod0=40, jitter_meshlets=True, max_lods=3, seed=9)
@@ -106,6 +108,7 @@ def test_animated_transforms_then_cull(oracle):
     with _Ctx((640, 360)) as r:
         r.load_scene(scene.instances, scene.meshData, scene.meshlets, scene.opaqueIds, scene.alphaMaskIds)
         r.load_nodes(nodes, prim_to_node)
+        r.set_renderer_queue("UpdateInstanceConstsRenderer", async_compute)
         r.set_culling(5)
         inst = scene.instances.copy()
         for frame in range(3):
@@ -123,6 +126,8 @@ def test_animated_transforms_then_cull(oracle):
             sc = dict(scene.as_oracle()); sc["instances"] = inst
             ref = oracle.frame(sc, view.as_dict(), hzb, None, cullingFlags=5, maxGroups=65535, record_capacity=65535)
             _compare(r.results(), ref)
+            fs = r.render_graph_frame_stats()
+            assert fs["compute_queue_passes"] == int(async_compute) and fs["cross_queue_waits"] == int(async_compute)
 
 
 def test_headline_config_subsample_spot_check(oracle):

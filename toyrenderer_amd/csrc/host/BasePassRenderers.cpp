@@ -95,10 +95,12 @@ class UpdateInstanceConstsRenderer : public IRenderer
 public:
     UpdateInstanceConstsRenderer() : IRenderer{ "UpdateInstanceConstsRenderer" } {}
 
-    bool Setup(RenderGraph&) override
+    bool Setup(RenderGraph& renderGraph) override
     {
         // :115-123 (returns false without primitives); static scenes skip the pass as well
-        return g_Scene->m_NumPrimitives != 0 && g_Scene->m_bUpdateInstanceTransforms;
+        if (g_Scene->m_NumPrimitives == 0 || !g_Scene->m_bUpdateInstanceTransforms) return false;
+        renderGraph.AddExternalWriteDependency(g_Scene->m_InstanceConstsBuffer.Get());   // async compute: see RenderGraph::Compile
+        return true;
     }
 
     void Render(nvrhi::CommandListHandle commandList, const RenderGraph&) override
@@ -180,6 +182,9 @@ public:
     {
         const uint32_t nbInstances = g_Scene->m_NumPrimitives;                // :225-229
         if (nbInstances == 0) return true;
+        // resources outside the graph this pass touches (for the cross-queue waits of RenderGraph::Compile)
+        renderGraph.AddExternalReadDependency(g_Scene->m_InstanceConstsBuffer.Get());
+        renderGraph.AddExternalWriteDependency(g_Scene->m_HZB.Get());
 
         m_DoFrustumCulling = g_Scene->m_bEnableFrustumCulling;                // :231-233
         m_bDoOcclusionCulling = g_Scene->m_bEnableOcclusionCulling;

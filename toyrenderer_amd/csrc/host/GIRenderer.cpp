@@ -29,6 +29,7 @@ public:
     {
         if (!g_Scene->m_bShowGIProbes || g_Scene->m_NumGIProbes == 0) return false;   // :661-670: only with DDGI and the debug view on
         const uint32_t numProbes = g_Scene->m_NumGIProbes;
+        renderGraph.AddExternalReadDependency(g_Scene->m_HZB.Get());          // :652 AddReadDependency(volume descs) in the reference
         {
             nvrhi::BufferDesc desc;                                           // :618-626
             desc.byteSize = sizeof(float) * 3ull * numProbes;

@@ -1,5 +1,7 @@
 // Graphic.cpp -- see Graphic.h.  Re-authored against the HIP back end; cites are to the reference's
 // source/Graphic.cpp and source/GraphicRHI.cpp.
+#include <unordered_map>
+
 #include "Graphic.h"
 
 #include "HostProfile.h"
@@ -30,7 +32,9 @@ nvrhi::DeviceHandle GraphicRHI::CreateDevice(int deviceIndex, void* externalHipS
     uint64_t mem = 0;
     nvrhi::throwIfFailed(trhip_device_info(dev, &cus, &wave, &mem), "trhip_device_info");
     check(wave == 2 * interop::kNumThreadsPerWave);
-    return nvrhi::DeviceHandle(new nvrhi::IDevice(dev));
+    nvrhi::DeviceHandle device(new nvrhi::IDevice(dev));
+    device->setDeviceIndex(deviceIndex);
+    return device;
 }
 
 Graphic& Graphic::GetInstance()
@@ -71,6 +75,7 @@ void Graphic::Shutdown()
     for (IRenderer* renderer : IRenderer::ms_AllRenderers) {
         renderer->m_FrameTimerQuery[0] = nullptr;
         renderer->m_FrameTimerQuery[1] = nullptr;
+        renderer->m_Queue = nvrhi::CommandQueue::Graphics;
     }
     m_Scene->Shutdown();
     m_Scene.reset();
@@ -79,9 +84,11 @@ void Graphic::Shutdown()
     m_GlobalMeshletDataBuffer = nullptr;
     m_GlobalVertexBuffer = nullptr; m_GlobalMeshletVertexOffsetsBuffer = nullptr; m_GlobalMeshletIndicesBuffer = nullptr;
     m_PendingCommandLists.clear();
-    m_FreeCommandLists.clear();
+    for (auto& pool : m_FreeCommandLists) pool.clear();
     m_AllCommandLists.clear();
+    m_NVRHIDevice->destroyQueues();
     m_NVRHIDevice = nullptr;
+    m_NumCrossQueueWaits = 0;
     m_FrameCounter = 0;
 }
 
@@ -103,15 +110,16 @@ bool Graphic::HasShader(std::string_view shaderBinName) const
     return trhip_shader_exists(std::string(shaderBinName).c_str()) != 0;
 }
 
-nvrhi::CommandListHandle Graphic::AllocateCommandList(nvrhi::CommandQueue)
+nvrhi::CommandListHandle Graphic::AllocateCommandList(nvrhi::CommandQueue queueType)
 {
-    std::lock_guard<std::mutex> lock(m_FreeCommandListsLock);                 // Graphic.cpp:520-555
-    if (!m_FreeCommandLists.empty()) {
-        nvrhi::CommandListHandle cl = m_FreeCommandLists.front();
-        m_FreeCommandLists.pop_front();
+    std::lock_guard<std::mutex> lock(m_FreeCommandListsLock);                 // Graphic.cpp:520-555 (one pool per queue type)
+    std::deque<nvrhi::CommandListHandle>& pool = m_FreeCommandLists[(size_t)queueType];
+    if (!pool.empty()) {
+        nvrhi::CommandListHandle cl = pool.front();
+        pool.pop_front();
         return cl;
     }
-    nvrhi::CommandListHandle cl = m_NVRHIDevice->createCommandList();
+    nvrhi::CommandListHandle cl = m_NVRHIDevice->createCommandList(queueType);
     m_AllCommandLists.push_back(cl);
     return cl;
 }
@@ -119,7 +127,7 @@ nvrhi::CommandListHandle Graphic::AllocateCommandList(nvrhi::CommandQueue)
 void Graphic::FreeCommandList(nvrhi::CommandListHandle cmdList)
 {
     std::lock_guard<std::mutex> lock(m_FreeCommandListsLock);
-    m_FreeCommandLists.push_back(cmdList);
+    m_FreeCommandLists[(size_t)cmdList->m_Queue].push_back(cmdList);
 }
 
 void Graphic::BeginCommandList(nvrhi::CommandListHandle cmdList, std::string_view name)
@@ -141,19 +149,51 @@ void Graphic::EndCommandList(nvrhi::CommandListHandle cmdList, bool bQueueCmdlis
 
 void Graphic::ExecuteAllCommandLists()
 {
-    std::vector<nvrhi::CommandListHandle> lists;
+    std::vector<PendingCommandList> lists;
     {
         std::lock_guard<std::mutex> lock(m_PendingCommandListsLock);
         lists.swap(m_PendingCommandLists);
     }
     if (lists.empty()) return;
-    // Graphic.cpp:790 does waitForIdle before every submit (upload-manager versioning).  The stream is
+    // Graphic.cpp:790 does waitForIdle before every submit (upload-manager versioning).  The streams are
     // in-order and recorded lists own their staging copies, so the wait is not needed for
     // correctness here and would only serialise CPU recording with GPU execution.
-    std::vector<nvrhi::ICommandList*> raw;
-    for (auto& cl : lists) raw.push_back(cl.Get());
-    m_NVRHIDevice->executeCommandLists(raw.data(), raw.size());               // Graphic.cpp:816
-    for (auto& cl : lists) FreeCommandList(cl);
+    //
+    // Lists are submitted in queue order (= pass order); runs of lists of one queue type go down in one call
+    // (Graphic.cpp:816).  A list that depends on a list of the OTHER queue (RenderGraph::Compile) first makes its queue
+    // wait for that one (nvrhi queueWaitForCommandList).  Frames are joined: whatever the compute queue still runs from
+    // the previous submission is awaited by this one's first graphics list and the other way round -- the graph does not
+    // see hazards across frames.
+    using Q = nvrhi::CommandQueue;
+    bool anyCompute = false;
+    for (const PendingCommandList& p : lists) anyCompute |= p.m_CommandList->m_Queue == Q::Compute;
+    if (anyCompute || m_NVRHIDevice->hasComputeQueue()) {
+        if (m_NVRHIDevice->hasComputeQueue() && m_NVRHIDevice->lastInstance(Q::Compute))
+            m_NVRHIDevice->queueWaitForCommandList(Q::Graphics, Q::Compute, m_NVRHIDevice->lastInstance(Q::Compute));
+        if (anyCompute && m_NVRHIDevice->lastInstance(Q::Graphics))
+            m_NVRHIDevice->queueWaitForCommandList(Q::Compute, Q::Graphics, m_NVRHIDevice->lastInstance(Q::Graphics));
+    }
+    std::unordered_map<const nvrhi::ICommandList*, std::pair<Q, uint64_t>> submitted;     // list -> (queue, instance)
+    size_t i = 0;
+    while (i < lists.size()) {
+        const Q queue = lists[i].m_CommandList->m_Queue;
+        for (const nvrhi::ICommandList* dep : lists[i].m_WaitFor) {
+            auto it = submitted.find(dep);
+            check(it != submitted.end());                                     // dependencies point backwards in queue order
+            if (it->second.first != queue) {
+                // the producer's queue is in order, so waiting for its LATEST submission covers the one meant
+                m_NVRHIDevice->queueWaitForCommandList(queue, it->second.first, m_NVRHIDevice->lastInstance(it->second.first));
+                ++m_NumCrossQueueWaits;
+            }
+        }
+        std::vector<nvrhi::ICommandList*> raw{ lists[i].m_CommandList.Get() };
+        size_t j = i + 1;
+        while (j < lists.size() && lists[j].m_CommandList->m_Queue == queue && lists[j].m_WaitFor.empty()) raw.push_back(lists[j++].m_CommandList.Get());
+        const uint64_t instance = m_NVRHIDevice->executeCommandLists(raw.data(), raw.size(), queue);   // Graphic.cpp:816
+        for (nvrhi::ICommandList* cl : raw) submitted[cl] = { queue, instance };
+        i = j;
+    }
+    for (auto& p : lists) FreeCommandList(p.m_CommandList);
 }
 
 void Graphic::AddComputePass(const ComputePassParams& p)

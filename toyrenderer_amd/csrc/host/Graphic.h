@@ -54,11 +54,14 @@ public:
     void BeginCommandList(nvrhi::CommandListHandle cmdList, std::string_view name);
     void EndCommandList(nvrhi::CommandListHandle cmdList, bool bQueueCmdlist, bool bImmediateExecute);
     void ExecuteAllCommandLists();
-    void QueueCommandList(nvrhi::CommandListHandle commandList)
+    // waitFor (this build, RenderGraph.cpp:251 "TODO: compute queue"): lists queued EARLIER whose work this list's queue
+    // must wait for when they run on another queue
+    void QueueCommandList(nvrhi::CommandListHandle commandList, std::vector<const nvrhi::ICommandList*> waitFor = {})
     {
         std::lock_guard<std::mutex> lock(m_PendingCommandListsLock);
-        m_PendingCommandLists.push_back(commandList);
+        m_PendingCommandLists.push_back(PendingCommandList{ commandList, std::move(waitFor) });
     }
+    uint64_t m_NumCrossQueueWaits = 0;                                       // stats: queueWaitForCommandList calls the graph asked for
 
     // Graphic.h:83-111
     struct AddPassParamsCommon
@@ -100,10 +103,11 @@ public:
 
 private:
     std::vector<nvrhi::CommandListHandle> m_AllCommandLists;
-    std::deque<nvrhi::CommandListHandle> m_FreeCommandLists;
+    std::deque<nvrhi::CommandListHandle> m_FreeCommandLists[(size_t)nvrhi::CommandQueue::Count];
     std::mutex m_FreeCommandListsLock;
     std::mutex m_PendingCommandListsLock;
-    std::vector<nvrhi::CommandListHandle> m_PendingCommandLists;
+    struct PendingCommandList { nvrhi::CommandListHandle m_CommandList; std::vector<const nvrhi::ICommandList*> m_WaitFor; };
+    std::vector<PendingCommandList> m_PendingCommandLists;
 };
 #define g_Graphic Graphic::GetInstance()
 
@@ -122,6 +126,9 @@ public:
     virtual void Render(nvrhi::CommandListHandle commandList, const RenderGraph& renderGraph) = 0;
 
     const std::string m_Name;
+    // Which queue the pass records for (this build; the reference has the graphics queue only, RenderGraph.cpp:251).
+    // Compute: the pass runs on the second stream, concurrently with graphics-queue passes it shares no resource with.
+    nvrhi::CommandQueue m_Queue = nvrhi::CommandQueue::Graphics;
     float m_CPUFrameTime = 0.0f;
     float m_GPUFrameTime = 0.0f;
     nvrhi::TimerQueryHandle m_FrameTimerQuery[2];

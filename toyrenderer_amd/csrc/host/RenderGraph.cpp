@@ -102,6 +102,31 @@ void RenderGraph::Compile()
         }
     }
 
+    // ---- this build: cross-queue waits (async compute).  Pass i waits for an earlier pass j on another queue when they
+    // touch a common resource and at least one of the two writes it (read-after-write, write-after-write,
+    // write-after-read).  Queues are in order, so the LATEST such j per foreign queue is enough.
+    m_FrameStats = FrameStats{};
+    for (size_t i = 0; i < m_Passes.size(); ++i) {
+        Pass& pi = m_Passes[i];
+        pi.m_WaitForPasses.clear();
+        const nvrhi::CommandQueue qi = pi.m_CommandList->m_Queue;
+        if (qi == nvrhi::CommandQueue::Compute) ++m_FrameStats.m_NumComputeQueuePasses;
+        for (size_t j = i; j-- > 0;) {
+            const Pass& pj = m_Passes[j];
+            if (pj.m_CommandList->m_Queue == qi) continue;
+            bool hazard = false;
+            for (const ResourceAccess& a : pi.m_ResourceAccesses)
+                for (const ResourceAccess& b : pj.m_ResourceAccesses)
+                    hazard |= a.m_ResourceHandle == b.m_ResourceHandle &&
+                              (a.m_AccessType == ResourceHandle::AccessType::Write || b.m_AccessType == ResourceHandle::AccessType::Write);
+            for (const ExternalAccess& a : pi.m_ExternalAccesses)
+                for (const ExternalAccess& b : pj.m_ExternalAccesses)
+                    hazard |= a.m_Resource == b.m_Resource &&
+                              (a.m_AccessType == ResourceHandle::AccessType::Write || b.m_AccessType == ResourceHandle::AccessType::Write);
+            if (hazard) { pi.m_WaitForPasses.push_back((PassID)j); ++m_FrameStats.m_NumCrossQueueWaits; break; }
+        }
+    }
+
     // age out transient resources nobody asked for during the last frames (:123-135)
     for (ResourceHandle* h : m_ResourceHandles) {
         check(h->m_AllocatedFrameIdx != UINT32_MAX);
@@ -151,6 +176,20 @@ void RenderGraph::Compile()
     // heap ranges released this frame become free only now (:211-220)
     for (const HeapToFree& e : m_HeapsToFree) m_Heaps.at(e.m_Idx).Free(e.m_Offset);
     m_HeapsToFree.clear();
+
+    // ---- this build: what lifetime aliasing would save (statistics only).  Peak over the passes of the bytes of the
+    // resources live at that pass = the optimum for interval-shaped lifetimes.
+    std::vector<uint64_t> liveAtPass(m_Passes.size() + 1, 0);
+    for (ResourceHandle* h : m_ResourceHandles) {
+        if (!h->m_Resource || h->m_FirstAccess == kInvalidPassID) continue;
+        uint64_t bytes = 0;
+        if (h->m_Type == ResourceHandle::Type::Texture) bytes = device->getTextureMemoryRequirements((nvrhi::ITexture*)h->m_Resource.Get()).size;
+        else bytes = device->getBufferMemoryRequirements((nvrhi::IBuffer*)h->m_Resource.Get()).size;
+        bytes = AlignUp64(bytes, kHeapAlignment);
+        m_FrameStats.m_TransientBytes += bytes;
+        for (size_t p = h->m_FirstAccess; p <= h->m_LastAccess && p < m_Passes.size(); ++p) liveAtPass[p] += bytes;
+    }
+    for (uint64_t b : liveAtPass) m_FrameStats.m_AliasedBytes = std::max(m_FrameStats.m_AliasedBytes, b);
 }
 
 tf::Task RenderGraph::AddRenderer(IRenderer* renderer)
@@ -163,7 +202,7 @@ tf::Task RenderGraph::AddRenderer(IRenderer* renderer)
 
     if (!renderer->Setup(*this)) {                                            // :237-248
         // a renderer that opts out must not have registered any access
-        check(m_Passes.back().m_ResourceAccesses.empty());
+        check(m_Passes.back().m_ResourceAccesses.empty() && m_Passes.back().m_ExternalAccesses.empty());
         m_Passes.pop_back();
         renderer->m_CPUFrameTime = 0.0f;
         renderer->m_GPUFrameTime = 0.0f;
@@ -171,7 +210,7 @@ tf::Task RenderGraph::AddRenderer(IRenderer* renderer)
     }
 
     m_Passes.back().m_Renderer = renderer;
-    m_Passes.back().m_CommandList = g_Graphic.AllocateCommandList();          // :251
+    m_Passes.back().m_CommandList = g_Graphic.AllocateCommandList(renderer->m_Queue);   // :251 "TODO: compute queue": the renderer's choice
 
     tf::Task renderTask = m_TaskFlow->emplace([this, passIdx] {               // :254-288
         tl_CurrentThreadPassID = passIdx;
@@ -201,7 +240,9 @@ tf::Task RenderGraph::AddRenderer(IRenderer* renderer)
     tf::Task queueTask = m_TaskFlow->emplace([this, passIdx] {                // :291-299
         Pass& pass = m_Passes.at(passIdx);
         check(pass.m_CommandList);
-        g_Graphic.QueueCommandList(pass.m_CommandList);
+        std::vector<const nvrhi::ICommandList*> waitFor;                      // cross-queue hazards found by Compile()
+        for (PassID j : pass.m_WaitForPasses) waitFor.push_back(m_Passes.at(j).m_CommandList.Get());
+        g_Graphic.QueueCommandList(pass.m_CommandList, std::move(waitFor));
     });
     queueTask.succeed(renderTask);
     m_CommandListQueueTasks.push_back(queueTask);
@@ -257,6 +298,17 @@ void RenderGraph::AddDependencyInternal(ResourceHandle& h, ResourceHandle::Acces
     std::vector<ResourceAccess>& accesses = m_Passes.back().m_ResourceAccesses;
     for (const ResourceAccess& a : accesses) check(a.m_ResourceHandle != &h);  // one dependency per pass and resource
     accesses.push_back(ResourceAccess{ &h, accessType });
+}
+
+void RenderGraph::AddExternalDependencyInternal(const nvrhi::IResource* resource, ResourceHandle::AccessType accessType)
+{
+    check(m_CurrentPhase == Phase::Setup);
+    check(!m_Passes.empty());
+    if (!resource) return;
+    std::vector<ExternalAccess>& accesses = m_Passes.back().m_ExternalAccesses;
+    for (ExternalAccess& a : accesses)
+        if (a.m_Resource == resource) { if (accessType == ResourceHandle::AccessType::Write) a.m_AccessType = accessType; return; }
+    accesses.push_back(ExternalAccess{ resource, accessType });
 }
 
 nvrhi::IResource* RenderGraph::GetResourceInternal(const ResourceHandle& h, ResourceHandle::Type type) const

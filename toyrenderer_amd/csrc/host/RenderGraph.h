@@ -40,7 +40,16 @@ public:
 
     struct ResourceDesc { nvrhi::TextureDesc m_TextureDesc; nvrhi::BufferDesc m_BufferDesc; };
     struct ResourceAccess { ResourceHandle* m_ResourceHandle; ResourceHandle::AccessType m_AccessType; };
-    struct Pass { IRenderer* m_Renderer = nullptr; std::vector<ResourceAccess> m_ResourceAccesses; nvrhi::CommandListHandle m_CommandList; };
+    // m_ExternalAccesses / m_WaitForPasses: this build (async compute queue, RenderGraph.cpp:251 "TODO: compute queue")
+    struct ExternalAccess { const nvrhi::IResource* m_Resource; ResourceHandle::AccessType m_AccessType; };
+    struct Pass
+    {
+        IRenderer* m_Renderer = nullptr;
+        std::vector<ResourceAccess> m_ResourceAccesses;
+        nvrhi::CommandListHandle m_CommandList;
+        std::vector<ExternalAccess> m_ExternalAccesses;
+        std::vector<PassID> m_WaitForPasses;          // earlier passes on ANOTHER queue this pass has a hazard with
+    };
 
     // RenderGraph.h:56-74: free-list allocator over one device heap
     struct Heap
@@ -68,6 +77,10 @@ public:
     void CreateTransientResource(ResourceHandle& resourceHandle, const ResourceDescT& resourceDesc);
     void AddReadDependency(ResourceHandle& resourceHandle) { AddDependencyInternal(resourceHandle, ResourceHandle::AccessType::Read); }
     void AddWriteDependency(ResourceHandle& resourceHandle) { AddDependencyInternal(resourceHandle, ResourceHandle::AccessType::Write); }
+    // this build: accesses to resources the graph does not own (scene buffers, the HZB).  On one queue the queue order
+    // covers them, as in the reference; with passes on two queues the graph needs them to place the cross-queue waits.
+    void AddExternalReadDependency(const nvrhi::IResource* resource) { AddExternalDependencyInternal(resource, ResourceHandle::AccessType::Read); }
+    void AddExternalWriteDependency(const nvrhi::IResource* resource) { AddExternalDependencyInternal(resource, ResourceHandle::AccessType::Write); }
 
     // Execute-phase functions
     [[nodiscard]] nvrhi::TextureHandle GetTexture(const ResourceHandle& resourceHandle) const { return (nvrhi::ITexture*)GetResourceInternal(resourceHandle, ResourceHandle::Type::Texture); }
@@ -76,11 +89,19 @@ public:
     // introspection for tests / stats (the reference shows these in an ImGui table, Scene.cpp:530-562)
     const std::vector<Heap>& GetHeaps() const { return m_Heaps; }
     size_t GetNumPasses() const { return m_Passes.size(); }
+    // Of the last compiled frame: passes on the compute queue, cross-queue waits derived from the declared accesses,
+    // bytes of the live transient resources, and the bytes a lifetime-aliasing allocator would need for them (resources
+    // whose [first, last] pass ranges do not overlap sharing memory; the reference, like this build, places every
+    // transient resource for the whole frame -- RenderGraph.cpp:139-208 -- and shows no such number).
+    struct FrameStats { uint32_t m_NumComputeQueuePasses = 0, m_NumCrossQueueWaits = 0; uint64_t m_TransientBytes = 0, m_AliasedBytes = 0; };
+    const FrameStats& GetFrameStats() const { return m_FrameStats; }
     // this build: upper bound of one transient resource (the reference asserts 1 GB, RenderGraph.cpp:158)
     static uint64_t ms_MaxHeapBlockSize;
 
 private:
     void AddDependencyInternal(ResourceHandle& resourceHandle, ResourceHandle::AccessType accessType);
+    void AddExternalDependencyInternal(const nvrhi::IResource* resource, ResourceHandle::AccessType accessType);
+    FrameStats m_FrameStats;
     nvrhi::IResource* GetResourceInternal(const ResourceHandle& resourceHandle, ResourceHandle::Type resourceType) const;
     void FreeResource(ResourceHandle& resourceHandle);
     const char* GetResourceName(const ResourceHandle& resourceHandle) const;

@@ -275,7 +275,8 @@ struct ComputeState
 class ICommandList : public IResource
 {
 public:
-    explicit ICommandList(trhip_cmdlist cl) : m_Native(cl) {}
+    explicit ICommandList(trhip_cmdlist cl, CommandQueue queue = CommandQueue::Graphics) : m_Queue(queue), m_Native(cl) {}
+    const CommandQueue m_Queue;                      // CommandListParameters::queueType
     ~ICommandList() override { trhip_cmd_release(m_Native); }
     trhip_cmdlist native() const { return m_Native; }
 
@@ -365,8 +366,17 @@ class IDevice : public IResource
 {
 public:
     explicit IDevice(trhip_device d) : m_Native(d) {}
-    ~IDevice() override { trhip_device_destroy(m_Native); }
+    ~IDevice() override { destroyQueues(); trhip_device_destroy(m_Native); }
     trhip_device native() const { return m_Native; }
+    trhip_device queueDevice(CommandQueue queue)
+    {
+        if (queue != CommandQueue::Compute) return m_Native;
+        if (!m_ComputeNative) {
+            throwIfFailed(trhip_stream_create(m_DeviceIndex, &m_ComputeStream), "IDevice: compute-queue stream");
+            throwIfFailed(trhip_device_create_on_stream(m_DeviceIndex, m_ComputeStream, &m_ComputeNative), "IDevice: compute-queue device");
+        }
+        return m_ComputeNative;
+    }
 
     HeapHandle createHeap(const HeapDesc& d)
     {
@@ -408,20 +418,51 @@ public:
     }
     bool bindBufferMemory(IBuffer* b, IHeap* h, uint64_t off) { throwIfFailed(trhip_buffer_bind_memory(b->native(), h->native(), off), "IDevice::bindBufferMemory"); return true; }
     bool bindTextureMemory(ITexture* t, IHeap* h, uint64_t off) { throwIfFailed(trhip_texture_bind_memory(t->native(), h->native(), off), "IDevice::bindTextureMemory"); return true; }
-    CommandListHandle createCommandList()
+    // nvrhi::CommandListParameters::queueType.  The COMPUTE queue (the reference never creates one: GraphicRHI.cpp:152-177
+    // has a single graphics queue, RenderGraph.cpp:251 says "TODO: compute queue") is a second back-end device on the
+    // same GPU with a stream of its own, created on first use.
+    CommandListHandle createCommandList(CommandQueue queue = CommandQueue::Graphics)
     {
         trhip_cmdlist cl = nullptr;
-        throwIfFailed(trhip_cmd_create(m_Native, &cl), "IDevice::createCommandList");
-        return CommandListHandle(new ICommandList(cl));
+        throwIfFailed(trhip_cmd_create(queueDevice(queue), &cl), "IDevice::createCommandList");
+        return CommandListHandle(new ICommandList(cl, queue));
     }
-    void executeCommandLists(ICommandList* const* lists, size_t n)
+    // nvrhi executeCommandLists: returns the instance id of the submission on that queue
+    uint64_t executeCommandLists(ICommandList* const* lists, size_t n, CommandQueue queue = CommandQueue::Graphics)
     {
         std::vector<trhip_cmdlist> v;
-        for (size_t i = 0; i < n; ++i) v.push_back(lists[i]->native());
-        throwIfFailed(trhip_queue_execute(m_Native, v.data(), (uint32_t)v.size()), "IDevice::executeCommandLists");
+        for (size_t i = 0; i < n; ++i) { check(lists[i]->m_Queue == queue); v.push_back(lists[i]->native()); }
+        throwIfFailed(trhip_queue_execute(queueDevice(queue), v.data(), (uint32_t)v.size()), "IDevice::executeCommandLists");
+        return ++m_LastInstance[(size_t)queue];
     }
-    void executeCommandList(ICommandList* cl) { executeCommandLists(&cl, 1); }
-    void waitForIdle() { throwIfFailed(trhip_device_wait_idle(m_Native), "IDevice::waitForIdle"); }
+    uint64_t executeCommandList(ICommandList* cl) { return executeCommandLists(&cl, 1, cl->m_Queue); }
+    // nvrhi queueWaitForCommandList: everything submitted to `waitQueue` from now on runs after submission `instance` of
+    // `executionQueue` (which must be its latest: the event is recorded here, behind the producer's internal side stream)
+    void queueWaitForCommandList(CommandQueue waitQueue, CommandQueue executionQueue, uint64_t instance)
+    {
+        if (waitQueue == executionQueue) return;
+        check(instance == m_LastInstance[(size_t)executionQueue]);
+        trhip_device producer = queueDevice(executionQueue);
+        void*& ev = m_QueueEvents[(size_t)executionQueue][instance % kQueueEvents];
+        if (!ev) throwIfFailed(trhip_event_create(m_DeviceIndex, &ev), "IDevice::queueWaitForCommandList: event");
+        throwIfFailed(trhip_device_join_side_stream(producer), "IDevice::queueWaitForCommandList: join");
+        throwIfFailed(trhip_event_record(ev, trhip_device_stream(producer)), "IDevice::queueWaitForCommandList: record");
+        throwIfFailed(trhip_stream_wait_event(trhip_device_stream(queueDevice(waitQueue)), ev), "IDevice::queueWaitForCommandList: wait");
+    }
+    uint64_t lastInstance(CommandQueue queue) const { return m_LastInstance[(size_t)queue]; }
+    bool hasComputeQueue() const { return m_ComputeNative != nullptr; }
+    void setDeviceIndex(int index) { m_DeviceIndex = index; }
+    void waitForIdle()
+    {
+        throwIfFailed(trhip_device_wait_idle(m_Native), "IDevice::waitForIdle");
+        if (m_ComputeNative) throwIfFailed(trhip_device_wait_idle(m_ComputeNative), "IDevice::waitForIdle (compute queue)");
+    }
+    void destroyQueues()
+    {
+        for (auto& q : m_QueueEvents) for (void*& e : q) { if (e) trhip_event_destroy(e); e = nullptr; }
+        if (m_ComputeNative) { trhip_device_destroy(m_ComputeNative); m_ComputeNative = nullptr; }
+        if (m_ComputeStream) { trhip_stream_destroy(m_ComputeStream); m_ComputeStream = nullptr; }
+    }
     void runGarbageCollection() {}
     TimerQueryHandle createTimerQuery()
     {
@@ -439,7 +480,13 @@ public:
     void resetTimerQuery(ITimerQuery* q) { if (q) q->m_Recorded = false; }
 
 private:
+    static constexpr size_t kQueueEvents = 16;
     trhip_device m_Native;
+    trhip_device m_ComputeNative = nullptr;
+    void* m_ComputeStream = nullptr;
+    int m_DeviceIndex = 0;
+    uint64_t m_LastInstance[(size_t)CommandQueue::Count] = {};
+    void* m_QueueEvents[(size_t)CommandQueue::Count][kQueueEvents] = {};
 };
 using DeviceHandle = RefCountPtr<IDevice>;
 

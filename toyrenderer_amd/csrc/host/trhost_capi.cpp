@@ -265,6 +265,27 @@ int trhost_exchange_outputs(uint32_t pass_slot, void** records, void** masks, vo
 }
 int trhost_exchange_destroy(void) { return guarded([&] { ShardExchangeDestroy(); }); }
 
+int trhost_set_renderer_queue(const char* renderer_name, int queue)
+{
+    return guarded([&] {
+        check(renderer_name && (queue == 0 || queue == 1));
+        for (IRenderer* r : IRenderer::ms_AllRenderers)
+            if (r->m_Name == renderer_name) { r->m_Queue = queue ? nvrhi::CommandQueue::Compute : nvrhi::CommandQueue::Graphics; return; }
+        throw nvrhi::Error(std::string("no renderer named ") + renderer_name);
+    });
+}
+
+int trhost_render_graph_frame_stats(uint32_t* compute_queue_passes, uint32_t* cross_queue_waits, uint64_t* transient_bytes, uint64_t* aliased_bytes)
+{
+    return guarded([&] {
+        const RenderGraph::FrameStats& f = g_Scene->m_RenderGraph->GetFrameStats();
+        if (compute_queue_passes) *compute_queue_passes = f.m_NumComputeQueuePasses;
+        if (cross_queue_waits) *cross_queue_waits = f.m_NumCrossQueueWaits;
+        if (transient_bytes) *transient_bytes = f.m_TransientBytes;
+        if (aliased_bytes) *aliased_bytes = f.m_AliasedBytes;
+    });
+}
+
 int trhost_render_graph_stats(uint32_t* num_heaps, uint64_t* bytes_reserved, uint64_t* bytes_used, uint32_t* num_passes)
 {
     return guarded([&] {

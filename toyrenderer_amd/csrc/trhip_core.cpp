@@ -319,6 +319,18 @@ int trhip_device_wait_idle(trhip_device dev)
     return dev->syncAll();
 }
 
+int trhip_device_join_side_stream(trhip_device dev)
+{
+    if (!dev) return fail(TRHIP_ERR_INVALID, "device is null");
+    TRHIP_HIP(hipSetDevice(dev->index));
+    std::lock_guard<std::mutex> lock(dev->mutex);
+    if (dev->sideStream && dev->sideRunCounter > dev->mainWaitedUpTo) {
+        TRHIP_HIP(hipStreamWaitEvent(dev->stream, dev->runDone[dev->sideRunCounter % trhip_device_t::kSideRuns], 0));
+        dev->mainWaitedUpTo = dev->sideRunCounter;      // the side stream is in order: earlier runs are covered too
+    }
+    return TRHIP_OK;
+}
+
 int trhip_device_info(trhip_device dev, uint32_t* cus, uint32_t* wave, uint64_t* mem)
 {
     if (!dev) return fail(TRHIP_ERR_INVALID, "device is null");

@@ -23,6 +23,7 @@ HOST_SYMBOLS = [
     "trhost_rccl_allgather", "trhost_exchange_create", "trhost_exchange_run", "trhost_exchange_wait", "trhost_exchange_outputs",
     "trhost_exchange_destroy", "trhost_load_geometry", "trhost_set_raster_depth", "trhost_download_depth",
     "trhost_load_scene_cached", "trhost_scene_list_sizes", "trhost_rccl_allreduce_max_u32", "trhost_load_gi_probes", "trhost_gi_probe_buffers",
+    "trhost_set_renderer_queue", "trhost_render_graph_frame_stats",
 ]
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)   # trhost_allgather_fn
@@ -87,6 +88,8 @@ def load() -> C.CDLL:
     L.trhost_exchange_create.argtypes = [C.POINTER(ExchangeDesc)]
     L.trhost_scene_list_sizes.argtypes = [C.POINTER(u32), C.POINTER(u32)]
     L.trhost_load_gi_probes.argtypes = [vp, vp, u32, C.c_float, C.c_int]
+    L.trhost_set_renderer_queue.argtypes = [C.c_char_p, C.c_int]
+    L.trhost_render_graph_frame_stats.argtypes = [C.POINTER(u32), C.POINTER(u32), C.POINTER(u64), C.POINTER(u64)]
     L.trhost_gi_probe_buffers.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.trhost_exchange_outputs.argtypes = [u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.trhost_set_shard_late_exchange.argtypes = [SHARD_LATE_FN, vp]
@@ -283,6 +286,15 @@ class Renderer:
         nh, res, used, npass = C.c_uint32(), C.c_uint64(), C.c_uint64(), C.c_uint32()
         _check(load().trhost_render_graph_stats(C.byref(nh), C.byref(res), C.byref(used), C.byref(npass)))
         return dict(heaps=nh.value, reserved=res.value, used=used.value, passes=npass.value)
+
+    def set_renderer_queue(self, name: str, compute: bool):
+        """Async compute: the renderer records for the compute queue (a second stream) instead of the graphics queue."""
+        _check(load().trhost_set_renderer_queue(name.encode(), int(bool(compute))))
+
+    def render_graph_frame_stats(self):
+        a, b, c, d = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_uint64()
+        _check(load().trhost_render_graph_frame_stats(C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(compute_queue_passes=a.value, cross_queue_waits=b.value, transient_bytes=c.value, aliased_bytes=d.value)
 
     def renderer_times(self, name: str):
         c, g = C.c_float(), C.c_float()

@@ -22,7 +22,7 @@ BIND_CONSTANT_BUFFER, BIND_PUSH_CONSTANTS, BIND_STRUCTURED_SRV, BIND_STRUCTURED_
 ABI_SYMBOLS = [
     "trhip_last_error", "trhip_abi_version", "trhip_shader_count", "trhip_shader_name", "trhip_shader_exists",
     "trhip_device_create", "trhip_device_create_on_stream", "trhip_device_destroy", "trhip_device_wait_idle",
-    "trhip_device_info", "trhip_device_stream",
+    "trhip_device_info", "trhip_device_stream", "trhip_device_join_side_stream",
     "trhip_heap_create", "trhip_heap_release",
     "trhip_buffer_create", "trhip_buffer_wrap", "trhip_buffer_memory_requirements", "trhip_buffer_bind_memory",
     "trhip_buffer_retain", "trhip_buffer_release", "trhip_buffer_device_ptr", "trhip_buffer_size",
