@@ -134,6 +134,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--flags", type=int, default=7, help="culling flags (7 = frustum+occlusion+cone, the headline config)")
+    ap.add_argument("--animate", action="store_true",
+                    help="diagnostic (BASELINE configs[4]): a node hierarchy drives the instance transforms; every frame runs "
+                         "updateinstanceconsts + the instance-cache rebuild before the cull (node data resident: uploaded once)")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="diagnostic: this single process plays rank 0 of M (its shard of the scene, a 1-rank RCCL group for the exchange); "
                          "the printed line is NOT a bench result")
@@ -192,6 +195,10 @@ def main():
                       max_groups=record_cap, max_transient_bytes=8 << 30)
     dev = rhi.Device(handle=r.device())
     (i0, i1), n_local, n_total = build_shard(spec, shard_rank, shard_world, r, threads=min(8, host_threads()))
+    if args.animate:
+        nodes, prim_to_node = synth.animated_nodes(spec, 0)
+        r.load_nodes(nodes, prim_to_node)              # uploaded with the first frame, then resident
+        del nodes
     r.set_culling(args.flags)
     r.set_gpu_timers(False)          # the per-renderer timer queries are instrumentation (2 timestamp packets each)
     r.upload_depth(depth)
@@ -352,6 +359,9 @@ def main():
         out["collective"] = gather.collective if gather is not None else None     # "rccl-direct" | "pg" | "host-staged" | "loopback"
         if args.emulate_ranks > 1:
             out["metric"] = f"DIAGNOSTIC (rank 0 of {args.emulate_ranks} emulated on one GPU) - not a bench result"
+        if args.animate or args.config != "C3":
+            out["metric"] = (f"DIAGNOSTIC ({args.config}{', instance transforms rebuilt from the node hierarchy every frame' if args.animate else ''}) "
+                             "- Gmeshlets/s culled, not the headline config")
         if gather_checked is not None:
             out["gather_checked"] = gather_checked
     sync()

@@ -105,9 +105,12 @@ public:
 
     void Render(nvrhi::CommandListHandle commandList, const RenderGraph&) override
     {
-        {
-            PROFILE_GPU_SCOPED(commandList, "Upload Node Transforms");         // :127-130
+        if (g_Scene->m_bNodeLocalTransformsDirty) {
+            // :127-130 uploads the whole array every frame; here only when the application changed it (375 MB on the
+            // 1 B-meshlet config): the update dispatch below runs every frame either way (Prev = World, World = new)
+            PROFILE_GPU_SCOPED(commandList, "Upload Node Transforms");
             commandList->writeBuffer(g_Scene->m_NodeLocalTransformsBuffer, g_Scene->m_NodeLocalTransforms.data(), g_Scene->m_NodeLocalTransforms.size());
+            g_Scene->m_bNodeLocalTransformsDirty = false;
         }
         const uint32_t numPrimitives = g_Scene->m_NumPrimitives;
         UpdateInstanceConstsPassConstants passConstants;

@@ -162,6 +162,7 @@ void Scene::LoadNodes(const void* nodes, uint32_t numNodes, const uint32_t* prim
     m_PrimitiveIDToNodeIDBuffer = device->createBuffer(p);
     nvrhi::throwIfFailed(trhip_buffer_upload(m_PrimitiveIDToNodeIDBuffer->native(), 0, primitiveToNode, p.byteSize), "Scene upload");
     m_bUpdateInstanceTransforms = true;
+    m_bNodeLocalTransformsDirty = true;
 }
 
 void Scene::LoadGIProbes(const float* positions, const float* states, uint32_t numProbes, float probeRadius, bool hideInactive)

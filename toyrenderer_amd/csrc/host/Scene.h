@@ -69,6 +69,7 @@ public:
     std::vector<uint32_t> m_OpaquePrimitiveIDs, m_AlphaMaskPrimitiveIDs;
     std::vector<uint8_t> m_NodeLocalTransforms;      // NodeLocalTransform[] (host copy, uploaded every frame)
     uint32_t m_NumNodes = 0;
+    bool m_bNodeLocalTransformsDirty = false;        // the host copy changed since UpdateInstanceConstsRenderer last uploaded it
 
     // Scene.h:152-162
     nvrhi::BufferHandle m_InstanceConstsBuffer;

@@ -126,6 +126,7 @@ int trhost_set_node_transforms(const void* node_local_transforms, uint32_t num_n
     return guarded([&] {
         check(num_nodes == g_Scene->m_NumNodes);
         std::memcpy(g_Scene->m_NodeLocalTransforms.data(), node_local_transforms, (size_t)num_nodes * sizeof(interop::NodeLocalTransform));
+        g_Scene->m_bNodeLocalTransformsDirty = true;
     });
 }
 

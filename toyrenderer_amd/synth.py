@@ -248,6 +248,29 @@ def make_scene(spec: SceneSpec) -> Scene:
     return Scene(spec, inst, md, ml, op, am, total)
 
 
+def animated_nodes(spec: SceneSpec, frame: int, groups: int = 4096, nodes: np.ndarray | None = None):
+    """Node hierarchy of the animated configs (BASELINE configs[4]): one node per instance hanging below one of `groups`
+    group nodes; every frame all rotations, scales and positions change (seeded by `frame`).  Returns
+    (NodeLocalTransform[n + groups], primitive -> node)."""
+    n = spec.num_instances
+    if nodes is None:
+        nodes = np.zeros(n + groups, I.NodeLocalTransform)
+        nodes["m_ParentNodeIdx"][:n] = n + _rng(spec.seed, 11, 0).integers(0, groups, n)
+        nodes["m_ParentNodeIdx"][n:] = 0xFFFFFFFF
+    r = _rng(spec.seed, 12, frame)
+    q = r.standard_normal((n + groups, 4), dtype=np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    nodes["m_Rotation"] = q
+    nodes["m_Scale"][:n] = r.uniform(0.5, 2.0, (n, 1)).astype(np.float32)
+    nodes["m_Scale"][n:] = 1.0
+    nodes["m_Position"][:n] = r.standard_normal((n, 3), dtype=np.float32) * np.float32(3.0)
+    gp = np.empty((groups, 3), np.float32)
+    gp[:, 0] = r.uniform(-spec.box_x, spec.box_x, groups); gp[:, 1] = r.uniform(-spec.box_y, spec.box_y, groups)
+    gp[:, 2] = -r.uniform(spec.z_near, spec.z_far, groups)
+    nodes["m_Position"][n:] = gp
+    return nodes, np.arange(n, dtype=np.uint32)
+
+
 # ----------------------------------------------------------------------------- named configs
 def config_spec(name: str) -> SceneSpec:
     """BASELINE.json configs made concrete."""
@@ -262,6 +285,8 @@ def config_spec(name: str) -> SceneSpec:
                          alpha_mask_fraction=0.1)
     if name == "C3":   # 100 M unique meshlets, 781 250 x 128, one LOD (tested count exact)
         return SceneSpec(num_meshes=781_250, num_instances=781_250, meshlets_lod0=128, max_lods=1, unique=True)
+    if name == "C4":   # BASELINE configs[4] at full size: 1 B unique meshlets, 7 812 500 x 128 (32 GB of MeshletData: fits one 288-GB MI355X)
+        return SceneSpec(num_meshes=7_812_500, num_instances=7_812_500, meshlets_lod0=128, max_lods=1, unique=True)
     if name == "C4r":  # one rank's share of C4 (1 B meshlets over 8 GPUs): 125 M unique meshlets; transforms animated by the caller
         return SceneSpec(num_meshes=976_562, num_instances=976_562, meshlets_lod0=128, max_lods=1, unique=True)
     if name == "C3e":  # 1/8 of C3: the per-GPU share of the 8-GPU run (overhead proxy on one GPU)
