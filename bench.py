@@ -324,13 +324,18 @@ def main():
         # only valid for the exact workload it was measured on
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r1", "traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r2", "traffic.json")))
             if tj["config"] == args.config and tj["culling_flags"] == args.flags and tj["kernel"] == DOMINANT and world == 1:
                 traffic = int(tj["hbm_bytes_per_launch"])
         except (OSError, KeyError, ValueError):
             pass
+        # the whole frame against the same roofline (32 B per meshlet tested + 24 B per group record written
+        # and read + 72 B per instance processed + 4 B per visible meshlet) / frame time
+        frame_alg = 32 * tested_all + 24 * groups_all + 72 * (spec.num_instances + int(res.get("lateCount", 0))) + 4 * visible_all
+        frame_frac = frame_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS if world == 1 else None
         roofline = dict(bound="hbm", kernel=DOMINANT, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, avg_launch_ms=round(avg_ms, 4),
+                        frame_frac=round(frame_frac, 4) if frame_frac is not None else None, frame_algorithmic_bytes=int(frame_alg),
                         # against what a streaming-read kernel reaches on this part (tools/membw.hip, profiles/r1/membw_calibration.txt)
                         frac_of_measured_stream=round(achieved / MEASURED_STREAM_GBS, 4), measured_stream_peak=MEASURED_STREAM_GBS,
                         algorithmic_bytes_per_launch=int(alg_bytes), meshlets_per_launch=int(t0_tested),

@@ -51,30 +51,36 @@ constexpr uint32_t kBlock = 256;
 constexpr uint32_t kWaves = kBlock / 64;
 constexpr uint32_t kBatch = 64;                  // records per wave batch
 constexpr uint32_t kSteps = kBatch / 2;          // two records per wave step
+#ifndef TR_RING_SLOTS
+#define TR_RING_SLOTS 3      /* steps of MeshletData in flight per wave (2 KB each, staged in LDS) */
+#endif
 #ifndef TR_CULL_BATCH
-#define TR_CULL_BATCH 32     /* 64: 47 KB of LDS per workgroup, 3 per CU, 0.511 ms on C3; 32: 34 KB, 4 per CU, 0.482 ms; 16: 0.498 ms */
+/* records per wave and prologue: a multiple of 2 * TR_RING_SLOTS.  Measured on C3 with 2 ring slots: 64 records (47 KB of
+ * LDS per workgroup, 3 workgroups per CU) 0.511 ms, 32 (34 KB, 4 per CU) 0.482 ms, 16 (5 per CU) 0.498 ms. */
+#define TR_CULL_BATCH (TR_RING_SLOTS == 3 ? 30 : 32)
 #endif
 constexpr uint32_t kCullBatch = TR_CULL_BATCH;   // meshlet cull: records a wave resolves per prologue (<= 64: one per lane)
 constexpr uint32_t kCullSteps = kCullBatch / 2;
+constexpr uint32_t kRingSlots = TR_RING_SLOTS;
+static_assert(kCullSteps % kRingSlots == 0 && kCullBatch <= 64, "a batch is a whole number of trips round the ring");
 #ifndef TR_CULL_WAVES
 #define TR_CULL_WAVES 4
 #endif
 constexpr uint32_t kCullWaves = TR_CULL_WAVES;   // meshlet cull: waves per workgroup (= per window of 64 * kCullWaves... records)
 constexpr uint32_t kCullBlock = 64 * kCullWaves;
-constexpr uint32_t kSlowCap = 64;                // per wave and batch: lookups deferred to the texel path (see OccQuad::slow)
+constexpr uint32_t kSlowCap = 32;                // per wave and batch: lookups deferred to the texel path (see OccQuad::slow)
 
-struct RecordInfo                                 // per-record invariants parked in LDS (112 B, read as 128-bit words)
+struct RecordInfo                                 // per-record invariants parked in LDS (96 B, read as 128-bit words)
 {
     float wxy[8];                                 // world matrix rows 0..3: (x, y) pairs (8-byte aligned: read as packed operands)
     float wz[4];                                  //                         z column
     float adjxy[6];                               // MakeAdjugateMatrix rows 0..2: (x, y) pairs
     float adjz[3];                                //                               z column
     float maxScale;
-    const MeshletData* first;                     // &meshlets[m_MeshletDataBufferIdx + m_MeshletGroupOffset] (the buffer's start when count == 0)
+    uint32_t first;                               // m_MeshletDataBufferIdx + m_MeshletGroupOffset (0 when count == 0)
     uint32_t count;                               // lanes with meshletIdx < m_NumMeshlets (0..32)
-    uint32_t pad[3];
 };
-static_assert(sizeof(RecordInfo) == 112 && offsetof(RecordInfo, first) == 88, "RecordInfo layout");
+static_assert(sizeof(RecordInfo) == 96, "RecordInfo layout");
 
 __device__ __forceinline__ cm::M43P worldOf(const RecordInfo& ri)
 {
@@ -136,13 +142,13 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 //
 // LDS layout of a ring slot (2 KB per wave): [0,512) record A chunks 0-31, [512,1024) record B chunks 0-31,
 // [1024,1536) record A chunks 32-63, [1536,2048) record B chunks 32-63.
-__device__ __forceinline__ void issueMeshletLoads(char* slotLds /* wave-uniform */, const MeshletData* first, uint32_t count, uint32_t sub)
+__device__ __forceinline__ void issueMeshletLoads(char* slotLds /* wave-uniform */, const MeshletData* meshlets, uint32_t firstIdx, uint32_t count, uint32_t sub)
 {
     // Every lane always loads (chunks past the record's end re-read chunk 0): the number of loads in flight never
     // depends on the data.
     const uint32_t nChunks = count * 2u;
     const uint32_t ja = sub < nChunks ? sub : 0u, jb = 32u + sub < nChunks ? 32u + sub : 0u;
-    const char* p = reinterpret_cast<const char*>(first);
+    const char* p = reinterpret_cast<const char*>(meshlets + firstIdx);
     const char* pa = p + 16u * ja;                                                   // basepass.hlsl:65
     const char* pb = p + 16u * jb;
     const uint32_t ldsOff = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)slotLds;
@@ -172,14 +178,14 @@ __global__ __launch_bounds__(kCullBlock) void meshletCullKernel(MeshletCullArgs 
     unsigned long long stampLast = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-    __shared__ RecordInfo s_recAll[kCullWaves][kCullBatch + 4];           // + 4: the prefetch of the last two steps reads past the batch (count 0)
+    __shared__ RecordInfo s_recAll[kCullWaves][kCullBatch + 2 * kRingSlots];   // + 2 per ring slot: the prefetch of the last steps reads past the batch (count 0)
     __shared__ uint32_t s_gIdxAll[kCullWaves][kCullBatch];
     __shared__ uint32_t s_quadOff[16];                 // texel path: mip offsets
     __shared__ uint4 s_mipTab[17];                     // table path: per-mip constants indexed by exponent + 1 (cm::occTailQuad)
     __shared__ uint32_t s_slowAll[kCullWaves][kSlowCap];
     __shared__ uint32_t s_slowCount[kCullWaves];
     __shared__ uint32_t s_maskAll[kCullWaves][kCullBatch];
-    __shared__ __attribute__((aligned(16))) char s_ring[kCullWaves][2][2048];   // per wave: two ring slots of staged MeshletData
+    __shared__ __attribute__((aligned(16))) char s_ring[kCullWaves][kRingSlots][2048];   // per wave: the ring slots of staged MeshletData
 
     const uint32_t G = groupCount(a);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(kCullBlock) void meshletCullKernel(MeshletCullArgs 
     // the fast arithmetic path wants nearPlane in [2^-20, 2^20] (cm::stepQuotients)
     const bool nearInRange = a.k.m_NearPlane >= 0x1p-20f && a.k.m_NearPlane <= 0x1p20f;
     if (tid < kCullWaves) s_slowCount[tid] = 0;
-    if (lane < 4) { s_recAll[wave][kCullBatch + lane].first = a.meshlets; s_recAll[wave][kCullBatch + lane].count = 0; }
+    if (lane < 2 * kRingSlots) { s_recAll[wave][kCullBatch + lane].first = 0; s_recAll[wave][kCullBatch + lane].count = 0; }
     uint32_t* s_slow = s_slowAll[wave];
     uint32_t* s_mask = s_maskAll[wave];
     __syncthreads();                                                                 // the only workgroup barrier
@@ -238,14 +244,13 @@ __global__ __launch_bounds__(kCullBlock) void meshletCullKernel(MeshletCullArgs 
         // steps of this window that still hold records for this wave (wave-uniform), rounded up to even
         const uint32_t remaining = G - sbBase - 2 * waveInTeam;
         uint32_t nSteps = (remaining + 2 * teamWaves - 1) / (2 * teamWaves);
-        nSteps = nSteps < kCullSteps ? (nSteps + 1u) & ~1u : kCullSteps;
+        nSteps = nSteps < kCullSteps ? (nSteps + kRingSlots - 1u) / kRingSlots * kRingSlots : kCullSteps;   // whole trips round the ring
         TR_STAMP(0);   // between batches
         // ---- prologue: lane l resolves its record (basepass.hlsl:52-58) through the instance cull cache: ONE
         //      level of dependent loads here -- the entry itself was fetched while the previous batch ran ------
         {
             RecordInfo ri;
-            ri.count = 0; ri.first = a.meshlets; ri.maxScale = 0.f;
-            ri.pad[0] = ri.pad[1] = ri.pad[2] = 0;
+            ri.count = 0; ri.first = 0; ri.maxScale = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) ri.wxy[i] = 0.f;
 #pragma unroll
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(kCullBlock) void meshletCullKernel(MeshletCullArgs 
                 cnt = cnt < 32u ? cnt : 32u;
                 if (base + cnt > a.numMeshlets) cnt = 0;                             // never read outside the meshlet buffer
                 ri.count = cnt;
-                if (cnt) ri.first = a.meshlets + base;
+                if (cnt) ri.first = (uint32_t)base;                                  // < numMeshlets <= 2^32 (recordASMain)
             }
             if (lane < kCullBatch) s_rec[lane] = ri;
         }
@@ -297,20 +302,21 @@ __global__ __launch_bounds__(kCullBlock) void meshletCullKernel(MeshletCullArgs 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         TR_STAMP(1);   // prologue
-        // ---- main loop: two records per step, their MeshletData staged in LDS two steps ahead ---------------------
-        // Loads outstanding at the top of a step: {this slot's 2, the other slot's 2}; after the step's table lookup and
-        // its prefetch: {other slot's 2, lookup, this slot's 2}.  Both waits are therefore vmcnt(2).
-        char* const ringA = s_ring[__builtin_amdgcn_readfirstlane((int)wave)][0];
-        char* const ringB = ringA + 2048;
+        // ---- main loop: two records per step, their MeshletData staged in LDS kRingSlots steps ahead --------------
+        // Loads outstanding at the top of a step: 2 per ring slot, this step's slot first; after the step's table lookup and
+        // its prefetch: {the other slots' 2 each, lookup, this slot's 2}.  Hence the two waits: vmcnt(2 * (slots - 1))
+        // at the top, vmcnt(2) for the lookup.
+        char* const ring = s_ring[__builtin_amdgcn_readfirstlane((int)wave)][0];
         const uint32_t ringOff = (sub < 16u ? 0u : 512u) + half * 512u + sub * 32u;  // this lane's meshlet inside a ring slot
-        issueMeshletLoads(ringA, s_rec[half].first, s_rec[half].count, sub);
-        issueMeshletLoads(ringB, s_rec[2 + half].first, s_rec[2 + half].count, sub);
+#pragma unroll
+        for (uint32_t k = 0; k < kRingSlots; ++k)
+            issueMeshletLoads(ring + 2048u * k, a.meshlets, s_rec[2 * k + half].first, s_rec[2 * k + half].count, sub);
 
         auto step = [&](char* slot, uint32_t s) {
             TR_STAMP(7);   // loop overhead / previous tail
             const uint32_t r = 2 * s + half;                                         // record within the batch
             const RecordInfo& ri = s_rec[r];
-            TR_WAIT_VMCNT(2);                                                        // this slot has landed
+            if (kRingSlots == 3) TR_WAIT_VMCNT(4); else TR_WAIT_VMCNT(2);            // this slot has landed
             const v4f sph = *reinterpret_cast<const v4f*>(slot + ringOff);
             const uint32_t cone = *reinterpret_cast<const uint32_t*>(slot + ringOff + 16u);
             const float4 sphere = make_float4(sph.x, sph.y, sph.z, sph.w);
@@ -349,9 +355,9 @@ __global__ __launch_bounds__(kCullBlock) void meshletCullKernel(MeshletCullArgs 
                 if (vis & !os.accept)
                     asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "+v"(row0), "+v"(row1) : "v"(t0), "v"(t1) : "memory");
             }
-            // prefetch step s+2 into this slot (past the batch: the padding entries, a harmless re-read of meshlet 0 that
+            // prefetch step s + kRingSlots into this slot (past the batch: the padding entries, a harmless re-read of meshlet 0 that
             // keeps the loads unconditional).  The slot's LDS reads above have returned: their values were used.
-            issueMeshletLoads(slot, s_rec[r + 4].first, s_rec[r + 4].count, sub);
+            issueMeshletLoads(slot, a.meshlets, s_rec[r + 2 * kRingSlots].first, s_rec[r + 2 * kRingSlots].count, sub);
             TR_STAMP(4);   // lookup + prefetch issue
             // Loads are counted in order: "at most 2 outstanding" = everything before this step's prefetch has landed,
             // whether or not the wave issued its lookup.
@@ -381,11 +387,12 @@ __global__ __launch_bounds__(kCullBlock) void meshletCullKernel(MeshletCullArgs 
             TR_STAMP(6);   // ballot + mask store
         };
 #pragma unroll 1
-        for (uint32_t s = 0; s < nSteps; s += 2) {
-            step(ringA, s);
-            step(ringB, s + 1);
+        for (uint32_t s = 0; s < nSteps; s += kRingSlots) {
+            step(ring, s);
+            step(ring + 2048, s + 1);
+            if (kRingSlots == 3) step(ring + 4096, s + 2);
         }
-        TR_WAIT_VMCNT(0);                               // the last two (padding) prefetches: nothing may land in the ring later
+        TR_WAIT_VMCNT(0);                               // the last (padding) prefetches: nothing may land in the ring later
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (OCCLUSION && TABLE) {
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(kCullBlock) void meshletCullKernel(MeshletCullArgs 
                 auto exactVisible = [&](uint32_t r, uint32_t m) -> bool {
                     const RecordInfo& ri = s_rec[r];
                     if (m >= ri.count) return false;
-                    const float4* p = reinterpret_cast<const float4*>(ri.first);
+                    const float4* p = reinterpret_cast<const float4*>(a.meshlets + ri.first);
                     const float4 sphere = p[2u * m];
                     const uint32_t cone = __float_as_uint(p[2u * m + 1u].x);
                     const cm::F3 cv = cm::toViewP(cm::mulPointP({ sphere.x, sphere.y, sphere.z }, worldOf(ri)), VP);
@@ -909,6 +916,7 @@ int recordASMain(trhip::DispatchCtx& ctx)
     TRHIP_REQUIRE(visMask->byteSize / 4 >= a.recordCapacity, "%s: visMask holds %llu groups, records buffer %u", ctx.shaderName,
                   (unsigned long long)(visMask->byteSize / 4), a.recordCapacity);
     a.numMeshlets = meshlets->byteSize / sizeof(MeshletData);
+    TRHIP_REQUIRE(a.numMeshlets <= (1ull << 32), "%s: more than 2^32 meshlets (m_MeshletDataBufferIdx is 32 bits wide)", ctx.shaderName);
     a.visMask = (uint32_t*)visMask->ptr;
     a.visibleList = (uint32_t*)visList->ptr;
     const uint64_t lcap = visList->byteSize / 4;
@@ -930,8 +938,8 @@ int recordASMain(trhip::DispatchCtx& ctx)
 
     // Persistent grid: the group count lives on the device (indirect), so launch enough
     // workgroups to fill the chip and let them stride over the chunks.
-    // As many workgroups per CU as the LDS allows (34 KB each: 16 KB of per-record data + 16 KB of staged MeshletData):
-    // the kernel's pace is set by the bytes it keeps in flight (2 ring slots x 2 KB per wave), see issueMeshletLoads.
+    // As many workgroups per CU as the LDS allows (39.5 KB each: 13.5 KB of per-record data + 24 KB of staged MeshletData):
+    // the kernel's pace is set by the bytes it keeps in flight (3 ring slots x 2 KB per wave), see issueMeshletLoads.
     uint32_t blocksPerCU = 4u;
     if (const char* e = getenv("TRHIP_AS_BLOCKS_PER_CU")) blocksPerCU = (uint32_t)atoi(e) ? (uint32_t)atoi(e) : blocksPerCU;   // tuning experiments
     uint32_t grid = ctx.computeUnits() * blocksPerCU;
