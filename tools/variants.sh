@@ -13,9 +13,14 @@ if [ "$MODE" = build ]; then
   while [ -n "$1" ]; do
     name=$1; defs=$2; shift 2
     mkdir -p $LIB/exp/$name
-    /opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-function --offload-arch=gfx950 $defs -c $CS/k_basepass_as.hip -o $LIB/exp/$name/k_basepass_as.o
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $LIB/exp/$name/libtrhip.so $LIB/obj/trhip_core.o $LIB/obj/k_gpuculling.o $LIB/exp/$name/k_basepass_as.o $LIB/obj/k_hzb.o $LIB/obj/k_updateinstance.o $LIB/obj/k_raster.o $LIB/obj/k_giprobe.o
-    rm $LIB/exp/$name/k_basepass_as.o
+    F=${VFILE:-k_basepass_as}          # VFILE=k_gpuculling: the flags go to the instance-pass kernels instead
+    /opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-function --offload-arch=gfx950 $defs -c $CS/$F.hip -o $LIB/exp/$name/$F.o
+    OBJS=""
+    for o in trhip_core k_gpuculling k_basepass_as k_hzb k_updateinstance k_raster k_giprobe; do
+      if [ $o = $F ]; then OBJS="$OBJS $LIB/exp/$name/$F.o"; else OBJS="$OBJS $LIB/obj/$o.o"; fi
+    done
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $LIB/exp/$name/libtrhip.so $OBJS
+    rm $LIB/exp/$name/$F.o
     echo built $name "($defs)"
   done
 else

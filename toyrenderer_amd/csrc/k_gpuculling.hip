@@ -55,11 +55,10 @@ struct InstanceCullArgs
     uint32_t* bases;                // [0] X before the pass, [1] late count before the pass
     uint32_t numBlocks;
     // screen-tile binning of the submitted instances (PROCESSING order of the meshlet pass only; the
-    // record order above is untouched).  tileCount: 1024 counters (zeroed before classify), turned
-    // into cursors by the scan kernel; perm lives in the records buffer's sidecar: {valid, count, ...}
-    // header (64 words) followed by one record index per group.
-    uint32_t* tileCount;
-    uint32_t tileReplicas;          // kTileReplicas or kTileReplicasSmall
+    // record order above is untouched): a counting sort by tile, see "Large passes" below; perm lives in the records
+    // buffer's sidecar: {valid, count, ...} header (64 words) followed by one 16-byte entry per group.
+    uint32_t* tileHist;             // large passes: [workgroup][1024 tiles] groups per tile -> (scan) groups of the tile in earlier workgroups
+    uint32_t* tileTotal;            // [1024 tiles]
     uint16_t* tileOf;               // per entry
     uint2* lodSel;                  // per entry: {meshlets, first meshlet} of the LOD the instance was submitted at
     uint32_t* permHeader;
@@ -120,8 +119,6 @@ __global__ __launch_bounds__(256) void instanceCacheKernel(const BasePassInstanc
 
 constexpr uint32_t kTilesPerAxis = 32;
 constexpr uint32_t kNumTiles = kTilesPerAxis * kTilesPerAxis;
-constexpr uint32_t kTileReplicas = 32;            // counters are replicated (blockIdx % replicas) to spread the atomics: 32 for large
-constexpr uint32_t kTileReplicasSmall = 8;        // passes (781 k atomics on C3), 8 for small ones, where the scan over them is what costs
 constexpr uint32_t kPermHeaderWords = 64;
 #ifndef TR_MIN_BINNED
 #define TR_MIN_BINNED 4096
@@ -219,100 +216,131 @@ __device__ __forceinline__ uint32_t classify(const InstanceCullArgs& a, uint32_t
     return kWordSubmit | (lod << 27) | (groups & kGroupMask);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Large passes: classify -> scan -> emit, three launches, NO device-scope atomics (round 1 and the first half of round 2
+// counted the tile histogram and handed out the tile-run places with 2 x 440 k global atomics on C3, which paced both
+// kernels).  A workgroup of kBigThreads threads owns kBigChunk consecutive list entries:
+//   classify   per entry: the tests + LOD (classify<>), the word / block-local offset / tile / LOD selection to scratch;
+//              per workgroup: its sums and its tile histogram (LDS atomics) as row `block` of H[blocks][1024 tiles];
+//   scan       workgroup 0: exclusive scan of the workgroups' sums, final counters (what the reference's atomics
+//              leave), late-cull arguments; workgroups 1..64: sixteen tile columns of H each -> H[b][t] = groups
+//              of tile t in workgroups < b (64 stripes of workgroups, two walks), tile totals T[t];
+//   emit       per workgroup: run starts = exclusive scan of T + its row of H, kept as LDS cursors; records in canonical
+//              order, tile-ordered resolved entries at cursor positions (LDS atomics: the order inside a
+//              (workgroup, tile) run is arbitrary, which a PROCESSING order may be).
+// C3 (early 781 k entries, late ~100 k): 1024 x 2 entries per workgroup: early 49 + 6 + 24 us, late 14 + 7 + 26 us (too few
+// workgroups for the late list); 512 x 1: 37 + 13 + 23 / 7 + 5 + 6 us (shipped); 256 x 1: 36 + 21 + 25 / 7 + 5 + 8 us (the
+// histogram matrix the scan walks grows with the number of workgroups).  Round-1 scheme with global atomics: 47 + 11 + 30 / 6 + 10 + 12.
+#ifndef TR_BIG_THREADS
+#define TR_BIG_THREADS 512
+#endif
+#ifndef TR_BIG_PER
+#define TR_BIG_PER 1
+#endif
+constexpr uint32_t kBigThreads = TR_BIG_THREADS;
+constexpr uint32_t kBigPerThread = TR_BIG_PER;
+constexpr uint32_t kScanThreads = 1024;
+constexpr uint32_t kBigChunk = kBigThreads * kBigPerThread;
+constexpr uint32_t kBigWaves = kBigThreads / 64;
+constexpr uint32_t kScanTileGroups = 64;                   // scan workgroups 1..64
+constexpr uint32_t kScanTilesPerGroup = kNumTiles / kScanTileGroups;     // 16
+constexpr uint32_t kScanStripes = kScanThreads / kScanTilesPerGroup;     // 64
+
 template <int LATE>
-__global__ __launch_bounds__(kBlock) void instanceClassifyKernel(InstanceCullArgs a)
+__device__ __forceinline__ uint32_t activeBigBlocks(const InstanceCullArgs& a, uint32_t n)
 {
-    __shared__ uint32_t s_waveG[kBlock / 64];
-    __shared__ uint32_t s_waveL[kBlock / 64];
-    __shared__ uint32_t s_waveS[kBlock / 64];
+    const uint32_t need = (n + kBigChunk - 1) / kBigChunk;
+    return need < a.numBlocks ? need : a.numBlocks;
+}
 
+template <int LATE>
+__global__ __launch_bounds__(kBigThreads) void instanceClassifyKernel(InstanceCullArgs a)
+{
+    __shared__ uint32_t s_hist[kNumTiles];
+    __shared__ uint32_t s_waveG[kBigWaves], s_waveL[kBigWaves], s_waveS[kBigWaves];
     const uint32_t n = threadCount<LATE>(a);
-    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-
-    uint32_t word = 0, tile = 0;
-    uint2 lodSel = make_uint2(0u, 0u);
-    if (t < n) word = classify<LATE>(a, a.ids[t], &tile, &lodSel);
-
-    const uint32_t g = (word & kWordSubmit) ? (word & kGroupMask) : 0u;
-    if (g != 0 && n >= kMinBinnedEntries) {
-        a.lodSel[t] = lodSel;
-        // (Handing out the place inside the run here, from the value the update returns, and dropping the emit kernel's
-        // second round of atomics was tried: classify 39 -> 45 us, emit no faster.)
-        atomicAdd(&a.tileCount[tile * a.tileReplicas + (blockIdx.x % a.tileReplicas)], g);   // histogram of groups per screen tile
-        a.tileOf[t] = (uint16_t)tile;
-    }
-    const uint32_t late = word >> 31;
-    const uint32_t submit = (word >> 30) & 1u;
-
-    const uint32_t incG = waveInclusiveScan(g, lane);
-    const uint32_t incL = waveInclusiveScan(late, lane);
-    const uint32_t cntS = (uint32_t)__popcll(__ballot(submit != 0));
-    if (lane == 63) { s_waveG[wave] = incG; s_waveL[wave] = incL; s_waveS[wave] = cntS; }
-    __syncthreads();
-    uint32_t baseG = 0, baseL = 0, totG = 0, totL = 0, totS = 0;
+    if (blockIdx.x >= activeBigBlocks<LATE>(a, n)) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const bool binned = n >= kMinBinnedEntries;
+    for (uint32_t i = tid; i < kNumTiles; i += kBigThreads) s_hist[i] = 0;
+    uint32_t carryG = 0, carryL = 0, carryS = 0;
+    for (uint32_t e = 0; e < kBigPerThread; ++e) {
+        __syncthreads();                                   // histogram zeroed / the wave sums of the previous round consumed
+        const uint32_t t = blockIdx.x * kBigChunk + e * kBigThreads + tid;
+        uint32_t word = 0, tile = 0;
+        uint2 lodSel = make_uint2(0u, 0u);
+        if (t < n) word = classify<LATE>(a, a.ids[t], &tile, &lodSel);
+        const uint32_t g = (word & kWordSubmit) ? (word & kGroupMask) : 0u;
+        if (g != 0 && binned) {
+            atomicAdd(&s_hist[tile], g);                   // histogram of groups per screen tile (LDS)
+            a.tileOf[t] = (uint16_t)tile;
+            a.lodSel[t] = lodSel;
+        }
+        const uint32_t late = word >> 31;
+        const uint32_t submit = (word >> 30) & 1u;
+        const uint32_t incG = waveInclusiveScan(g, lane);
+        const uint32_t incL = waveInclusiveScan(late, lane);
+        const uint32_t cntS = (uint32_t)__popcll(__ballot(submit != 0));
+        if (lane == 63) { s_waveG[wave] = incG; s_waveL[wave] = incL; s_waveS[wave] = cntS; }
+        __syncthreads();
+        uint32_t baseG = 0, baseL = 0, totG = 0, totL = 0, totS = 0;
 #pragma unroll
-    for (uint32_t w = 0; w < kBlock / 64; ++w) {
-        if (w < wave) { baseG += s_waveG[w]; baseL += s_waveL[w]; }
-        totG += s_waveG[w]; totL += s_waveL[w]; totS += s_waveS[w];
+        for (uint32_t w = 0; w < kBigWaves; ++w) {
+            if (w < wave) { baseG += s_waveG[w]; baseL += s_waveL[w]; }
+            totG += s_waveG[w]; totL += s_waveL[w]; totS += s_waveS[w];
+        }
+        if (t < n) {
+            a.word[t] = word;
+            a.localOff[t] = late ? (carryL + baseL + incL - late) : (carryG + baseG + incG - g);
+        }
+        carryG += totG; carryL += totL; carryS += totS;
     }
-    if (t < n) {
-        a.word[t] = word;
-        a.localOff[t] = late ? (baseL + incL - late) : (baseG + incG - g);
-    }
-    if (threadIdx.x == 0) {
-        a.blockGroups[blockIdx.x] = totG;
-        a.blockLateSubmit[blockIdx.x] = (uint64_t)totL | ((uint64_t)totS << 32);
+    __syncthreads();
+    if (binned)
+        for (uint32_t i = tid; i < kNumTiles; i += kBigThreads) a.tileHist[(uint64_t)blockIdx.x * kNumTiles + i] = s_hist[i];
+    if (tid == 0) {
+        a.blockGroups[blockIdx.x] = carryG;
+        a.blockLateSubmit[blockIdx.x] = (uint64_t)carryL | ((uint64_t)carryS << 32);
     }
 }
 
-// One block: exclusive scan over the per-block sums; final counters.  Tiles of 1024 entries: wave
-// scans + one LDS exchange per tile; only the blocks that had threads (device-side count) are visited.
-template <int LATE, uint32_t REPLICAS>
-__global__ __launch_bounds__(1024) void instanceScanKernel(InstanceCullArgs a)
+template <int LATE>
+__global__ __launch_bounds__(kScanThreads) void instanceScanKernel(InstanceCullArgs a)
 {
-    __shared__ uint32_t s_wg[2][16];
-    __shared__ uint64_t s_wls[2][16];
-    __shared__ uint32_t s_carryG;
-    __shared__ uint64_t s_carryLS;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n = threadCount<LATE>(a);
-    const uint32_t activeBlocks = (n + kBlock - 1) / kBlock < a.numBlocks ? (n + kBlock - 1) / kBlock : a.numBlocks;
-    // Two workgroups, two independent jobs: 0 scans the per-block sums and closes the counters, 1 turns the tile histogram
-    // into run starts.
-    if (blockIdx.x == 1) {
-        // tile histogram -> exclusive prefix (run starts for the emit kernel); thread = tile, its replicas are contiguous
-        if (n >= kMinBinnedEntries) {
-            __shared__ uint32_t s_w[16];
-            uint32_t rep[REPLICAS];
-            uint32_t c = 0;
-#pragma unroll
-            for (uint32_t i = 0; i < REPLICAS; i += 4) {
-                const uint4 v = *reinterpret_cast<const uint4*>(&a.tileCount[tid * REPLICAS + i]);
-                rep[i] = v.x; rep[i + 1] = v.y; rep[i + 2] = v.z; rep[i + 3] = v.w;
-                c += v.x + v.y + v.z + v.w;
-            }
-            uint32_t inc = waveInclusiveScan(c, lane);
-            if (lane == 63) s_w[wave] = inc;
-            __syncthreads();
-            uint32_t pre = 0;
-            for (uint32_t w = 0; w < wave; ++w) pre += s_w[w];
-            uint32_t run = pre + inc - c;
-#pragma unroll
-            for (uint32_t i = 0; i < REPLICAS; i += 4) {
-                uint4 v;
-                v.x = run; run += rep[i];
-                v.y = run; run += rep[i + 1];
-                v.z = run; run += rep[i + 2];
-                v.w = run; run += rep[i + 3];
-                *reinterpret_cast<uint4*>(&a.tileCount[tid * REPLICAS + i]) = v;
-            }
+    const uint32_t activeBlocks = activeBigBlocks<LATE>(a, n);
+    if (blockIdx.x != 0) {
+        // ---- tile columns: H[b][t] <- groups of tile t in workgroups < b; T[t] <- all of them -------------------------
+        if (n < kMinBinnedEntries) return;
+        __shared__ uint32_t s_stripe[kScanStripes][kScanTilesPerGroup];
+        const uint32_t tl = tid % kScanTilesPerGroup, stripe = tid / kScanTilesPerGroup;
+        const uint32_t tile = (blockIdx.x - 1u) * kScanTilesPerGroup + tl;
+        const uint32_t per = (activeBlocks + kScanStripes - 1) / kScanStripes;
+        const uint32_t b0 = stripe * per < activeBlocks ? stripe * per : activeBlocks;
+        const uint32_t b1 = b0 + per < activeBlocks ? b0 + per : activeBlocks;
+        uint32_t sum = 0;
+        for (uint32_t b = b0; b < b1; ++b) sum += a.tileHist[(uint64_t)b * kNumTiles + tile];
+        s_stripe[stripe][tl] = sum;
+        __syncthreads();
+        uint32_t run = 0;
+        for (uint32_t sIdx = 0; sIdx < stripe; ++sIdx) run += s_stripe[sIdx][tl];
+        for (uint32_t b = b0; b < b1; ++b) {
+            const uint32_t v = a.tileHist[(uint64_t)b * kNumTiles + tile];
+            a.tileHist[(uint64_t)b * kNumTiles + tile] = run;
+            run += v;
         }
+        if (stripe == kScanStripes - 1u) a.tileTotal[tile] = run;
         return;
     }
+    // ---- workgroup 0: exclusive scan over the per-workgroup sums; final counters ------------------------------------
+    __shared__ uint32_t s_wg[2][(kScanThreads / 64)];
+    __shared__ uint64_t s_wls[2][(kScanThreads / 64)];
+    __shared__ uint32_t s_carryG;
+    __shared__ uint64_t s_carryLS;
     uint32_t carryG = 0, flip = 0;
     uint64_t carryLS = 0;
-    for (uint32_t base = 0; base < activeBlocks; base += 1024) {
+    for (uint32_t base = 0; base < activeBlocks; base += kScanThreads) {
         const uint32_t i = base + tid;
         const uint32_t g = i < activeBlocks ? a.blockGroups[i] : 0u;
         const uint64_t ls = i < activeBlocks ? a.blockLateSubmit[i] : 0ull;
@@ -325,7 +353,7 @@ __global__ __launch_bounds__(1024) void instanceScanKernel(InstanceCullArgs a)
         uint32_t preG = 0, totG = 0;
         uint64_t preLS = 0, totLS = 0;
 #pragma unroll
-        for (uint32_t w = 0; w < 16; ++w) {
+        for (uint32_t w = 0; w < (kScanThreads / 64); ++w) {
             const uint32_t xg = s_wg[flip][w];
             const uint64_t xl = s_wls[flip][w];
             if (w < wave) { preG += xg; preLS += xl; }
@@ -351,7 +379,7 @@ __global__ __launch_bounds__(1024) void instanceScanKernel(InstanceCullArgs a)
             a.dispatchArgs[1] = 1;
             a.dispatchArgs[2] = 1;
         }
-        if (a.argsWords > 3) a.dispatchArgs[3] = X;           // valid records; the first dropped instance lowers it in C
+        if (a.argsWords > 3) a.dispatchArgs[3] = X;           // valid records; the first dropped instance lowers it in emit
         if (!LATE) {
             const uint32_t late = baseLate + (uint32_t)s_carryLS;
             *a.lateCount = late;                                // :165
@@ -369,40 +397,63 @@ __global__ __launch_bounds__(1024) void instanceScanKernel(InstanceCullArgs a)
 }
 
 template <int LATE>
-__global__ __launch_bounds__(kBlock) void instanceEmitKernel(InstanceCullArgs a)
+__global__ __launch_bounds__(kBigThreads) void instanceEmitKernel(InstanceCullArgs a)
 {
+    __shared__ uint32_t s_cursor[kNumTiles];
+    __shared__ uint32_t s_wave[kBigWaves];
     const uint32_t n = threadCount<LATE>(a);
-    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-    if (t >= n) return;
-    const uint32_t word = a.word[t];
-    if (word & kWordLate) {                                                         // :162-167
-        const uint32_t idx = a.bases[1] + (uint32_t)a.blockLateSubmit[blockIdx.x] + a.localOff[t];
-        a.lateIds[idx] = a.ids[t];
-        return;
+    if (blockIdx.x >= activeBigBlocks<LATE>(a, n)) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const bool binned = n >= kMinBinnedEntries;
+    if (binned) {
+        // run start of (this workgroup, tile) = groups of the tiles before it + groups of this tile in earlier workgroups
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < kNumTiles; base += kBigThreads) {
+            const uint32_t tot = a.tileTotal[base + tid];
+            const uint32_t inc = waveInclusiveScan(tot, lane);
+            if (lane == 63) s_wave[wave] = inc;
+            __syncthreads();
+            uint32_t pre = 0, all = 0;
+            for (uint32_t w = 0; w < kBigWaves; ++w) { if (w < wave) pre += s_wave[w]; all += s_wave[w]; }
+            s_cursor[base + tid] = carry + pre + inc - tot + a.tileHist[(uint64_t)blockIdx.x * kNumTiles + base + tid];
+            carry += all;
+            __syncthreads();
+        }
     }
-    if (!(word & kWordSubmit)) return;
-    const uint32_t groups = word & kGroupMask;
-    const uint32_t lod = (word >> 27) & 7u;
-    const uint32_t off = a.bases[0] + a.blockGroups[blockIdx.x] + a.localOff[t];    // :65
-    if (off + groups >= a.maxGroups) {                                              // :69-74 (Q2)
-        if (groups != 0 && off < a.maxGroups && a.argsWords > 3) a.dispatchArgs[3] = off;
-        return;
-    }
-    const uint32_t id = a.ids[t];
-    for (uint32_t i = 0; i < groups; ++i) {                                         // :76-84
-        MeshletAmplificationData rec = { id, lod, i * kNumThreadsPerWave };
-        a.records[off + i] = rec;
-    }
-    if (groups != 0 && n >= kMinBinnedEntries) {                                    // slot range in the tile-sorted order
-        const uint32_t p = atomicAdd(&a.tileCount[(uint32_t)a.tileOf[t] * a.tileReplicas + (blockIdx.x % a.tileReplicas)], groups);
-        // the record resolved through the LOD table here, once per instance (basepass.hlsl:54-63): the meshlet cull then
-        // reads 16 bytes of this list and one 64-byte block of the instance cache per record, nothing else
-        const uint2 li = a.lodSel[t];
-        const uint32_t numMeshlets = li.x, base = li.y;
-        for (uint32_t i = 0; i < groups; ++i) {
-            const uint32_t first = i * kNumThreadsPerWave;
-            const uint32_t cnt = numMeshlets > first ? (numMeshlets - first < kNumThreadsPerWave ? numMeshlets - first : kNumThreadsPerWave) : 0u;
-            if (p + i < a.permCapacity) a.perm[p + i] = make_uint4(off + i, id, base + first, cnt);
+    const uint32_t baseG = a.bases[0] + a.blockGroups[blockIdx.x];
+    const uint32_t baseL = a.bases[1] + (uint32_t)a.blockLateSubmit[blockIdx.x];
+    for (uint32_t e = 0; e < kBigPerThread; ++e) {
+        const uint32_t t = blockIdx.x * kBigChunk + e * kBigThreads + tid;
+        if (t >= n) continue;
+        const uint32_t word = a.word[t];
+        if (word & kWordLate) {                                                         // :162-167
+            a.lateIds[baseL + a.localOff[t]] = a.ids[t];
+            continue;
+        }
+        if (!(word & kWordSubmit)) continue;
+        const uint32_t groups = word & kGroupMask;
+        const uint32_t lod = (word >> 27) & 7u;
+        const uint32_t off = baseG + a.localOff[t];                                     // :65
+        if (off + groups >= a.maxGroups) {                                              // :69-74 (Q2)
+            if (groups != 0 && off < a.maxGroups && a.argsWords > 3) a.dispatchArgs[3] = off;
+            continue;
+        }
+        const uint32_t id = a.ids[t];
+        for (uint32_t i = 0; i < groups; ++i) {                                         // :76-84
+            MeshletAmplificationData rec = { id, lod, i * kNumThreadsPerWave };
+            a.records[off + i] = rec;
+        }
+        if (groups != 0 && binned) {                                                    // place in the tile-ordered list
+            const uint32_t p = atomicAdd(&s_cursor[a.tileOf[t]], groups);
+            // the record resolved through the LOD table by classify, once per instance (basepass.hlsl:54-63): the meshlet
+            // cull then reads 16 bytes of this list and one 64-byte block of the instance cache per record, nothing else
+            const uint2 li = a.lodSel[t];
+            const uint32_t numMeshlets = li.x, base = li.y;
+            for (uint32_t i = 0; i < groups; ++i) {
+                const uint32_t first = i * kNumThreadsPerWave;
+                const uint32_t cnt = numMeshlets > first ? (numMeshlets - first < kNumThreadsPerWave ? numMeshlets - first : kNumThreadsPerWave) : 0u;
+                if (p + i < a.permCapacity) a.perm[p + i] = make_uint4(off + i, id, base + first, cnt);
+            }
         }
     }
 }
@@ -626,17 +677,19 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
     a.cache = instanceCacheLayout(instances->cullCache, instances->byteSize / sizeof(BasePassInstanceConstants));
     a.numInstances = (uint32_t)(instances->byteSize / sizeof(BasePassInstanceConstants));
     ctx.emit("instance_cache", [instances, meshData](hipStream_t s) { return trhip::instanceCacheLaunchBuild(instances, meshData, s); });
-    a.numBlocks = (nMax + kBlock - 1) / kBlock;
+    static const bool noFused = getenv("TRHIP_NO_FUSED_INSTANCE") != nullptr;          // tests: the three-kernel path on small passes
+    const bool fusedPath = nMax <= kFusedMaxEntries && !noFused;
+    a.numBlocks = fusedPath ? (nMax + kBlock - 1) / kBlock : (nMax + kBigChunk - 1) / kBigChunk;
     a.word = (uint32_t*)ctx.scratch((size_t)nMax * 4);
     a.localOff = (uint32_t*)ctx.scratch((size_t)nMax * 4);
     a.blockGroups = (uint32_t*)ctx.scratch((size_t)a.numBlocks * 4);
     a.blockLateSubmit = (uint64_t*)ctx.scratch((size_t)a.numBlocks * 8);
     a.bases = (uint32_t*)ctx.scratch(16);
-    a.tileReplicas = nMax >= (1u << 18) ? kTileReplicas : kTileReplicasSmall;
-    a.tileCount = (uint32_t*)ctx.scratch(kNumTiles * a.tileReplicas * 4);
+    a.tileHist = (uint32_t*)ctx.scratch(fusedPath ? 16 : (size_t)a.numBlocks * kNumTiles * 4);   // fully written by classify before scan reads it
+    a.tileTotal = (uint32_t*)ctx.scratch(kNumTiles * 4);
     a.tileOf = (uint16_t*)ctx.scratch((size_t)nMax * 2);
     a.lodSel = (uint2*)ctx.scratch((size_t)nMax * 8);
-    TRHIP_REQUIRE(a.word && a.localOff && a.blockGroups && a.blockLateSubmit && a.bases && a.tileCount && a.tileOf && a.lodSel, "%s: scratch allocation failed", ctx.shaderName);
+    TRHIP_REQUIRE(a.word && a.localOff && a.blockGroups && a.blockLateSubmit && a.bases && a.tileHist && a.tileTotal && a.tileOf && a.lodSel, "%s: scratch allocation failed", ctx.shaderName);
     // sidecar of the amplification buffer: header + one u32 per record slot
     {
         const uint64_t need = (uint64_t)kPermHeaderWords * 4 + (uint64_t)a.maxGroups * 16;
@@ -651,8 +704,6 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
         a.perm = (uint4*)(a.permHeader + kPermHeaderWords);
         a.permCapacity = a.maxGroups;
     }
-    rc = ctx.cl->recordClearWords(a.tileCount, kNumTiles * a.tileReplicas, 0, true);   // scratch of this pass: joins the recording's first clear launch
-    if (rc != TRHIP_OK) return rc;
     // The early meshlet cull that follows this pass resolves its HZB lookups through the footprint-min table of
     // this same HZB (k_hzb.hip): bring the table up to date on the side stream while the instance pass runs.
     if (!LATE && occlusion && a.maxGroups >= trhip::tableMinGroups()) {                 // the rule of recordASMain (k_basepass_as.hip)
@@ -660,8 +711,7 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
         if (rc != TRHIP_OK) return rc;
     }
 
-    static const bool noFused = getenv("TRHIP_NO_FUSED_INSTANCE") != nullptr;          // tests: the three-kernel path on small passes
-    if (nMax <= kFusedMaxEntries && !noFused) {
+    if (fusedPath) {
         const size_t words = (size_t)kFusedMaxTiles * kFusedStatusStride * 2 + 4;
         uint32_t* mem = (uint32_t*)ctx.scratch(words * 4);
         TRHIP_REQUIRE(mem, "%s: scratch allocation failed", ctx.shaderName);
@@ -677,15 +727,14 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
     }
 
     ctx.emit("classify", [a](hipStream_t s) {
-        hipLaunchKernelGGL(instanceClassifyKernel<LATE>, dim3(a.numBlocks), dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL(instanceClassifyKernel<LATE>, dim3(a.numBlocks), dim3(kBigThreads), 0, s, a);
         return trhip::launchStatus("instanceClassifyKernel"); });
     ctx.emit("scan", [a](hipStream_t s) {
-        if (a.tileReplicas == kTileReplicas) hipLaunchKernelGGL((instanceScanKernel<LATE, kTileReplicas>), dim3(2), dim3(1024), 0, s, a);
-        else hipLaunchKernelGGL((instanceScanKernel<LATE, kTileReplicasSmall>), dim3(2), dim3(1024), 0, s, a);
+        hipLaunchKernelGGL(instanceScanKernel<LATE>, dim3(1 + kScanTileGroups), dim3(kScanThreads), 0, s, a);
         return trhip::launchStatus("instanceScanKernel"); });
     const size_t scanOp = ctx.cl->ops.size() - 1;
     ctx.emit("emit", [a](hipStream_t s) {
-        hipLaunchKernelGGL(instanceEmitKernel<LATE>, dim3(a.numBlocks), dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL(instanceEmitKernel<LATE>, dim3(a.numBlocks), dim3(kBigThreads), 0, s, a);
         return trhip::launchStatus("instanceEmitKernel"); });
     if (!LATE && occlusion) ctx.cl->peephole = { ctx.cl->ops.size() - 1, "gpuculling_early", std::make_shared<EarlyCullNote>(EarlyCullNote{ a, scanOp, false }) };
     return TRHIP_OK;
@@ -715,8 +764,7 @@ int recordBuildLateArgs(trhip::DispatchCtx& ctx)
                     hipLaunchKernelGGL(instanceFusedKernel<0>, dim3(fused.numBlocks), dim3(kBlock), 0, s, fused);
                     return trhip::launchStatus("instanceFusedKernel"); };
             else ctx.cl->ops[scanOp].fn = [fused](hipStream_t s) {
-                if (fused.tileReplicas == kTileReplicas) hipLaunchKernelGGL((instanceScanKernel<0, kTileReplicas>), dim3(2), dim3(1024), 0, s, fused);
-                else hipLaunchKernelGGL((instanceScanKernel<0, kTileReplicasSmall>), dim3(2), dim3(1024), 0, s, fused);
+                hipLaunchKernelGGL(instanceScanKernel<0>, dim3(1 + kScanTileGroups), dim3(kScanThreads), 0, s, fused);
                 return trhip::launchStatus("instanceScanKernel"); };
             // this dispatch's accesses (count read, arguments written) now happen in the scan command
             for (size_t i = ctx.cl->useMarks.size(); i-- > 0 && ctx.cl->useMarks[i].op >= ctx.cl->ops.size();) ctx.cl->useMarks[i].op = scanOp;
