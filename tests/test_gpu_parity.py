@@ -453,3 +453,66 @@ def test_three_kernel_instance_pass_on_small_scenes():
                         "-k", "all_flag or late_dispatch or group_cap or two_frames or sweep or empty or forced"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+@pytest.mark.parametrize("flags,table", [(7, False), (7, True), (5, False), (3, True), (6, False)])
+def test_hostile_operands_take_the_exact_arithmetic_path(dev, oracle, flags, table):
+    """The cull kernel runs the square roots and divisions of a step on a fast path when every lane of the wave has its
+    operands in a comfortable exponent range and on the compiler's full IEEE sequences otherwise (cm::stepQuotients).
+    This scene makes sure the second path and the switch between them are exercised: world matrices with scales from
+    2^-45 to 2^40, a zero scale on one axis (zero adjugate rows: normalize(0 / 0)), meshlet radii of 0, 1e-38, 1e30 and
+    NaN, centres on the camera plane and behind it, at 1e20, infinities, cone bytes 0 / 127 / 128 / 255 -- mixed at
+    random with ordinary instances so that waves contain both kinds.  table: record capacity 2^19 (footprint-table
+    kernel) instead of the texel-path kernel.  Bit-exact against the oracle like every other case."""
+    from toyrenderer_amd.frame import FrameDriver, GpuScene
+    rng = np.random.default_rng(77 + flags)
+    spec = synth.SceneSpec(num_meshes=40, num_instances=900, meshlets_lod0=50, jitter_meshlets=True, max_lods=3, seed=4242)
+    scene = synth.make_scene(spec)
+    inst, ml = scene.instances, scene.meshlets
+    n = len(inst)
+    kind = rng.integers(0, 8, n)
+    W = inst["m_WorldMatrix"]
+    for i in range(n):
+        k = kind[i]
+        if k == 1: W[i, :3, :3] *= np.float32(2.0 ** rng.integers(-45, -30))
+        elif k == 2: W[i, :3, :3] *= np.float32(2.0 ** rng.integers(25, 40))
+        elif k == 3: W[i, int(rng.integers(0, 3)), :3] = 0.0                    # zero scale on one axis
+        elif k == 4: W[i, 3, :3] = rng.choice([0.0, 1e20, -1e20, 3e-39], 3).astype(np.float32)
+        elif k == 5: W[i, 3, 2] = np.float32(rng.choice([0.05, -0.05, 0.0, 5.0]))  # near / on / behind the camera plane
+    inst["m_PrevWorldMatrix"] = W
+    m = len(ml)
+    mk = rng.integers(0, 12, m)
+    sph = ml["m_BoundingSphere"]
+    sph[mk == 1, 3] = 0.0
+    sph[mk == 2, 3] = np.float32(1e-38)
+    sph[mk == 3, 3] = np.float32(1e30)
+    sph[mk == 4, 3] = np.nan
+    sph[mk == 5, :3] = np.float32(1e20)
+    sph[mk == 6, 0] = np.inf
+    sph[mk == 7, :3] = 0.0
+    cone = ml["m_ConeAxisAndCutoff"]
+    cone[mk == 8] = 0x00000000
+    cone[mk == 9] = 0xFF7F7F7F
+    cone[mk == 10] = 0x00808080
+    cone[mk == 11] = 0xFFFFFFFF
+    view = synth.make_view(eye=(0.2, 0.1, 0.4), yaw=0.02, render=(1280, 720))
+    d_prev = synth.gen_depth(view, num_occluders=50, seed=5, scale=3.0)
+    d_cur = synth.gen_depth(view, num_occluders=50, seed=6, scale=3.0)
+    cap = 1 << 19 if table else 65535
+    gs = GpuScene(dev, inst, scene.meshData, ml, scene.opaqueIds, scene.alphaMaskIds)
+    drv = FrameDriver(dev, gs, view, record_capacity=cap, culling_flags=flags)
+    hzb = _oracle_hzb(oracle, view, d_prev)
+    _upload_hzb(drv, hzb)
+    drv.depth.upload_mip(0, d_cur)
+    try:
+        with np.errstate(all="ignore"):
+            for _ in range(2):
+                drv.record()
+                drv.run()
+                got = drv.results()
+                ref = oracle.frame(scene.as_oracle(), view.as_dict(), hzb, d_cur, cullingFlags=flags, maxGroups=cap, record_capacity=cap)
+                _compare_frame(got, ref)
+        assert int(ref.meshletsTested[0]) > 5000 and 0 < int(ref.drawArgs[0][0]) < int(ref.meshletsTested[0])
+    finally:
+        drv.release()
+        gs.release()
