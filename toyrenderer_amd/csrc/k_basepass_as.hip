@@ -14,21 +14,24 @@
 //
 // This is the hot kernel of the path (32 B of MeshletData per meshlet tested).  Structure for
 // CDNA4 (DESIGN.md section 5 has the measurements behind each point):
-//   * the unit of work is a BATCH of 64 records owned by ONE wave64 (no workgroup barriers in the loop): lane l
-//     resolves its record through the instance cull cache (instance_cache.hip.h; the record itself comes from the
-//     permuted copy the instance pass wrote and is fetched while the previous batch runs), computes the adjugate
-//     and parks 96 B of per-record invariants in the wave's private LDS slice, (x, y) pairs first;
-//   * main loop, <= 32 steps: two records per step (lanes 0-31 / 32-63); per-record data are LDS broadcast
-//     reads; the meshlet stream is two coalesced, non-temporal 16-B loads per lane prefetched TWO steps ahead into
-//     a two-slot register ring that is pinned as 128-bit tuples, so every wait in the loop is partial;
+//   * a workgroup (4 waves) walks WINDOWS of 120 consecutive records of the tile-ordered list; a wave owns a BATCH of 30
+//     of them (no workgroup barriers in the loop): lane l resolves record l -- one level of dependent loads: the
+//     16-byte entry {record, instance, first meshlet, count} the instance pass wrote (fetched a batch ahead), then
+//     the instance's 64-byte block of the cull cache (instance_cache.hip.h) -- computes the adjugate and parks 96 B of
+//     per-record invariants in the wave's private LDS slice, (x, y) pairs first;
+//   * main loop, 15 steps: two records per step (lanes 0-31 / 32-63), per-record data are LDS broadcast reads; the
+//     MeshletData of a step (2 x 1 KB) goes from memory straight into a 3-slot LDS ring (global_load_lds_dwordx4, each
+//     cache line requested once), three steps ahead, and every lane reads ITS OWN meshlet from there; the ring's loads,
+//     the HZB lookup and their waits are hand-counted inline assembly (issueMeshletLoads below);
 //   * every test is evaluated branch-free and the result is the AND (the tests are pure, so this equals the
-//     reference's short-circuit order :73-108); the x / y halves of the projection, the 3x3 products and the cone
-//     decode run as packed fp32 pairs (same IEEE operation per component);
-//   * the HZB lookup is ONE 2-byte load from the footprint-min table (k_hzb.hip), issued before the prefetch and
-//     first used after the cone test; the rare lookups the table cannot serve are deferred to the texel path and
-//     patched into the batch's masks while those are still in LDS;
-//   * the loop issues no stores: the 64 masks of a batch (WaveActiveCountBits/WavePrefixCountBits :116-120 as
-//     ballots) are staged in LDS and leave in one store.
+//     reference's short-circuit order :73-108); transforms, projection halves, 3x3 products and the cone decode run as
+//     packed fp32 pairs, and all square roots and divisions of a step go through cm::stepQuotients: exact IEEE results
+//     without the v_div_scale / v_div_fmas / v_div_fixup glue whenever the whole wave's operands allow it;
+//   * the HZB lookup is ONE 2-byte load from the footprint-min table (k_hzb.hip, 8 x 8 blocks), only for lanes still
+//     in the race; the rare lookups the table cannot serve are deferred to the texel path and patched into the batch's
+//     masks while those are still in LDS;
+//   * the loop issues no stores: the 30 masks of a batch (WaveActiveCountBits/WavePrefixCountBits :116-120 = the two
+//     halves of the ballot) are staged in LDS and leave in one store.
 #include <algorithm>
 #include <cstdlib>
 #include <string>
