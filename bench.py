@@ -205,11 +205,12 @@ def main():
     gather = None
     if dist is not None:
         # one slot size for all ranks: the largest shard, every instance submitted at LOD 0
-        slot_groups = max(b - a for a, b in (shard_range(spec.num_instances, p, shard_world) for p in range(shard_world))) * groups_per_instance
+        slot_runs = max(b - a for a, b in (shard_range(spec.num_instances, p, shard_world) for p in range(shard_world)))   # one run per submitted instance
+        slot_groups = slot_runs * groups_per_instance
         loopback = args.emulate_ranks > 1 and bool(os.environ.get("TR_EMULATE_LOOPBACK"))   # diagnostic: the unpack sees M shards
         gather = NativeShardExchange(r, dist, shard_world if loopback else world, shard_rank if loopback else rank, slot_groups, pass_slots=(0, 1),
                                   group_capacity=spec.num_instances * groups_per_instance + (shard_world if loopback else 0) * groups_per_instance,
-                                  overlap=not os.environ.get("TR_NO_OVERLAP"), stage_through_host=backend != "nccl", loopback=loopback)
+                                  overlap=not os.environ.get("TR_NO_OVERLAP"), stage_through_host=backend != "nccl", loopback=loopback, slot_runs=slot_runs)
 
     rec_hist = []
     cpu_t = [0.0, 0.0, 0.0, 0.0]                          # host time spent submitting: frame, exchange (diagnostics, stderr only)

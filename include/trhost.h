@@ -136,6 +136,10 @@ typedef struct trhost_exchange_desc {
      * exchange + raster depth is rejected: per-rank HZBs would make the late and next-frame culls diverge from the
      * single-GPU frame. */
     int (*depth_allreduce_max)(void* user, void* depth_words, uint64_t count_words, void* hip_stream); void* depth_user;
+    /* run entries one rank's shard slot holds (the same on every rank): a run = the consecutive records of one
+     * submitted instance, so the number of id-list entries of the largest shard bounds it.  0: slot_groups (always
+     * enough).  Slot size = 16 + 4 * slot_runs + slot_groups words. */
+    uint32_t slot_runs;
 } trhost_exchange_desc;
 int  trhost_exchange_create(const trhost_exchange_desc* desc);   /* also installs the in-frame late-count hook      */
 int  trhost_exchange_run(void);                                  /* after trhost_frame: pack, gather, unpack (async) */

@@ -6,28 +6,56 @@ import numpy as np
 from toyrenderer_amd.gather import HEADER_WORDS, MAX_PASS_SLOTS, ShardExchange, slot_words
 
 
-def pack_shard_np(local: dict, slot_groups: int) -> np.ndarray:
+def runs_of_records_np(rec: np.ndarray) -> np.ndarray:
+    """u32[E,4] run entries {instance, lod, first group offset, index of the first record}: a record continues a run when
+    it repeats instance and lod and its group offset is the previous one + 32 (mod 2^32)."""
+    rec = np.asarray(rec, np.uint32).reshape(-1, 3)
+    if len(rec) == 0:
+        return np.zeros((0, 4), np.uint32)
+    cont = (rec[1:, 0] == rec[:-1, 0]) & (rec[1:, 1] == rec[:-1, 1]) & (rec[1:, 2] == rec[:-1, 2] + np.uint32(32))
+    first = np.concatenate([[0], np.nonzero(~cont)[0] + 1]).astype(np.uint32)
+    return np.concatenate([rec[first], first[:, None]], axis=1).astype(np.uint32)
+
+
+def records_of_runs_np(runs: np.ndarray, groups: int) -> np.ndarray:
+    """Inverse of runs_of_records_np for a pass slot of `groups` records."""
+    runs = np.asarray(runs, np.uint32).reshape(-1, 4)
+    out = np.zeros((groups, 3), np.uint32)
+    for e, (inst, lod, off0, first) in enumerate(runs):
+        nxt = int(runs[e + 1][3]) if e + 1 < len(runs) else groups
+        nxt, first = min(nxt, groups), int(first)
+        n = max(nxt - first, 0)
+        out[first:first + n, 0], out[first:first + n, 1] = inst, lod
+        out[first:first + n, 2] = (np.uint64(off0) + np.uint64(32) * np.arange(n, dtype=np.uint64)).astype(np.uint32)
+    return out
+
+
+def pack_shard_np(local: dict, slot_groups: int, slot_runs: int | None = None) -> np.ndarray:
     """local: pass slot -> (records u32[G,3], masks u32[G], V[, groups_counted]).  Returns the shard slot as
     u32 words.  groups_counted > G means the rank dropped groups at its capacity (header word 9)."""
-    out = np.zeros(slot_words(slot_groups), np.uint32)
-    start, overflow = 0, 0
-    rec_out = out[HEADER_WORDS:HEADER_WORDS + 3 * slot_groups]
-    mask_out = out[HEADER_WORDS + 3 * slot_groups:]
+    R = slot_groups if slot_runs is None else slot_runs
+    out = np.zeros(slot_words(slot_groups, R), np.uint32)
+    start, overflow, run_end = 0, 0, 0
+    run_out = out[HEADER_WORDS:HEADER_WORDS + 4 * R]
+    mask_out = out[HEADER_WORDS + 4 * R:]
     for s in range(MAX_PASS_SLOTS):
-        if s not in local:
-            continue
-        rec, masks, V = local[s][:3]
-        rec = np.asarray(rec, np.uint32).reshape(-1, 3)
-        g = len(rec)
-        if len(local[s]) > 3 and local[s][3] != g:
-            out[9] = 1
-        if start + g > slot_groups:
-            g, overflow = slot_groups - start, 1
-        rec_out[3 * start:3 * (start + g)] = rec[:g].reshape(-1)
-        mask_out[start:start + g] = np.asarray(masks, np.uint32)[:g]
-        out[2 * s], out[2 * s + 1] = g, V
-        start += g
-    out[8] = overflow
+        if s in local:
+            rec, masks, V = local[s][:3]
+            rec = np.asarray(rec, np.uint32).reshape(-1, 3)
+            g = len(rec)
+            if len(local[s]) > 3 and local[s][3] != g:
+                out[9] = 1
+            if start + g > slot_groups:
+                g, overflow = slot_groups - start, 1
+            runs = runs_of_records_np(rec[:g])
+            keep = max(min(len(runs), R - run_end), 0)
+            run_out[4 * run_end:4 * (run_end + keep)] = runs[:keep].reshape(-1)
+            run_end += len(runs)
+            mask_out[start:start + g] = np.asarray(masks, np.uint32)[:g]
+            out[2 * s], out[2 * s + 1] = g, V
+            start += g
+        out[10 + s] = run_end
+    out[8] = 1 if overflow or run_end > R else 0
     return out
 
 
@@ -39,9 +67,10 @@ def expand_masks_np(masks: np.ndarray) -> np.ndarray:
     return ((g.astype(np.uint32) << np.uint32(5)) | lane.astype(np.uint32)).astype(np.uint32)
 
 
-def unpack_shards_np(recv: np.ndarray, world: int, slot_groups: int, pass_slots, group_capacity: int) -> dict:
+def unpack_shards_np(recv: np.ndarray, world: int, slot_groups: int, pass_slots, group_capacity: int, slot_runs: int | None = None) -> dict:
     """recv: world x slot words.  Returns pass slot -> dict(records[G,3], masks[G], list[V], G, V, status)."""
-    recv = np.asarray(recv).view(np.uint32).reshape(world, slot_words(slot_groups))
+    R = slot_groups if slot_runs is None else slot_runs
+    recv = np.asarray(recv).view(np.uint32).reshape(world, slot_words(slot_groups, R))
     status = 0
     parts = {s: ([], []) for s in pass_slots}
     total = {s: 0 for s in pass_slots}
@@ -51,24 +80,29 @@ def unpack_shards_np(recv: np.ndarray, world: int, slot_groups: int, pass_slots,
             status |= 1
         if hdr[9]:
             status |= 8
-        rec = recv[p, HEADER_WORDS:HEADER_WORDS + 3 * slot_groups].reshape(-1, 3)
-        masks = recv[p, HEADER_WORDS + 3 * slot_groups:]
-        in_slot = 0
+        runs = recv[p, HEADER_WORDS:HEADER_WORDS + 4 * R].reshape(-1, 4)
+        masks = recv[p, HEADER_WORDS + 4 * R:]
+        in_slot, run_begin, bad = 0, 0, False
         for s in range(MAX_PASS_SLOTS):
-            g = int(hdr[2 * s]) if s in parts else 0
+            sent = int(hdr[2 * s])
+            g = sent if s in parts else 0
             src = in_slot
-            in_slot += g
-            if in_slot > slot_groups:
+            in_slot += sent
+            run_end = int(hdr[10 + s])
+            if in_slot > slot_groups or run_end < run_begin or run_end > R:
+                bad = True
+            if bad:
                 status |= 4
-                g = 0
-            if s not in parts:
-                continue
-            if total[s] + g > group_capacity:
-                g = group_capacity - total[s]
-                status |= 2
-            parts[s][0].append(rec[src:src + g])
-            parts[s][1].append(masks[src:src + g])
-            total[s] += g
+                g, run_end = 0, run_begin
+            if s in parts:
+                full = g
+                if total[s] + g > group_capacity:
+                    g = group_capacity - total[s]
+                    status |= 2
+                parts[s][0].append(records_of_runs_np(runs[run_begin:run_end], full)[:g])
+                parts[s][1].append(masks[src:src + g])
+                total[s] += g
+            run_begin = run_end
     out = {}
     for s in pass_slots:
         r = np.concatenate(parts[s][0]) if parts[s][0] else np.zeros((0, 3), np.uint32)
@@ -89,10 +123,10 @@ class NumpyShardExchange(ShardExchange):
         self.local = local
 
     def _pack(self, b):
-        self.send[b].copy_(self.torch.from_numpy(pack_shard_np(self.local, self.slot_groups).view(np.int32)))
+        self.send[b].copy_(self.torch.from_numpy(pack_shard_np(self.local, self.slot_groups, self.slot_runs).view(np.int32)))
 
     def _unpack(self, b):
-        res = unpack_shards_np(self.recv[b].numpy(), self.world, self.slot_groups, self.pass_slots, self.group_capacity)
+        res = unpack_shards_np(self.recv[b].numpy(), self.world, self.slot_groups, self.pass_slots, self.group_capacity, self.slot_runs)
         for s, r in res.items():
             o = self.out[s]
             o["records"][:3 * r["G"]] = self.torch.from_numpy(r["records"].reshape(-1).view(np.int32).copy())

@@ -62,7 +62,8 @@ def main():
             r.set_culling(7)
             r.upload_hzb(hzb.texels, hzb.offsets)
             r.upload_depth(d_cur)
-            ex = NativeShardExchange(r, dist, world, rank, slot_groups=cap, pass_slots=(0, 1, 2, 3), group_capacity=cap * world, stage_through_host=True)
+            ex = NativeShardExchange(r, dist, world, rank, slot_groups=cap, pass_slots=(0, 1, 2, 3), group_capacity=cap * world, stage_through_host=True,
+                                     slot_runs=len(op) + len(am))     # one run per submitted instance
             for f in range(3):
                 r.set_camera(view)
                 r.frame()

@@ -26,14 +26,28 @@ def dev():
     d.destroy()
 
 
-def _pack(dev, local, slot_groups, caps=None):
+def _pack_state(dev, slot_groups):
+    """u1 of visibility_CS_PackShard: two halves of 8-byte status words, zero before the first dispatch; every launch
+    uses one half and zeroes the other for the next launch on the same buffer."""
+    n = 4 * (slot_groups // 1024 + 5)
+    st = dev.create_buffer(4 * n, "packstate")
+    st.upload(np.zeros(n, np.uint32))
+    return st, n
+
+
+def _pack(dev, local, slot_groups, caps=None, slot_runs=None, repeat=1, state=None):
     """local: pass slot -> (records u32[G,3], masks u32[G], V).  Runs the HIP pack kernel, returns the slot words."""
     from toyrenderer_amd import rhi
+    R = slot_groups if slot_runs is None else slot_runs
+    W = gather.slot_words(slot_groups, R)
     bufs, binds = [], [rhi.PUSH(0)]
-    slot = dev.create_buffer(4 * gather.slot_words(slot_groups), "slot")
-    slot.upload(np.full(gather.slot_words(slot_groups), 0xDEADBEEF, np.uint32))
-    bufs.append(slot)
-    binds.append(rhi.UAV(0, slot))
+    slot = dev.create_buffer(4 * W, "slot")
+    slot.upload(np.full(W, 0xDEADBEEF, np.uint32))
+    bufs += [slot]
+    if state is None:                                   # else: a state buffer shared by consecutive packs, as in the host path
+        state, _ = _pack_state(dev, slot_groups)
+        bufs += [state]
+    binds += [rhi.UAV(0, slot), rhi.UAV(1, state)]
     for s, item in local.items():
         rec, masks, V = item[:3]
         G = len(rec)
@@ -47,19 +61,30 @@ def _pack(dev, local, slot_groups, caps=None):
         binds += [rhi.SRV(4 * s, r), rhi.SRV(4 * s + 1, m), rhi.SRV(4 * s + 2, a), rhi.SRV(4 * s + 3, d)]
     cl = dev.create_command_list()
     cl.open()
-    cl.dispatch("visibility_CS_PackShard", binds, (1, 1, 1), push=np.array([slot_groups], np.uint32))
+    cl.dispatch("visibility_CS_PackShard", binds, (1, 1, 1), push=np.array([slot_groups, R], np.uint32))
     cl.close()
-    dev.execute(cl)
+    for _ in range(repeat):                             # the recorded list is re-executed frame after frame
+        dev.execute(cl)
     dev.wait_idle()
-    out = slot.download(np.uint32, gather.slot_words(slot_groups))
+    out = slot.download(np.uint32, W)
     cl.release()
     for b in bufs:
         b.release()
     return out
 
 
-def _unpack(dev, recv, world, slot_groups, pass_slots, group_cap, list_cap):
+def _same_used_words(got, ref, S, R):
+    """Header, the run entries and the masks the reference wrote (the rest of the HIP slot keeps its fill pattern)."""
+    H = gather.HEADER_WORDS
+    runs, groups = min(int(ref[13]), R), int(ref[0] + ref[2] + ref[4] + ref[6])
+    return (np.array_equal(got[:H], ref[:H]) and np.array_equal(got[H:H + 4 * runs], ref[H:H + 4 * runs])
+            and np.array_equal(got[H + 4 * R:H + 4 * R + groups], ref[H + 4 * R:H + 4 * R + groups])
+            and np.all(got[H + 4 * runs:H + 4 * R] == 0xDEADBEEF) and np.all(got[H + 4 * R + groups:] == 0xDEADBEEF))
+
+
+def _unpack(dev, recv, world, slot_groups, pass_slots, group_cap, list_cap, slot_runs=None):
     from toyrenderer_amd import rhi
+    R = slot_groups if slot_runs is None else slot_runs
     rb = dev.buffer_from(np.asarray(recv, np.uint32), "recv")
     bufs, binds, outs = [rb], [rhi.PUSH(0), rhi.SRV(0, rb)], {}
     for s in pass_slots:
@@ -70,7 +95,7 @@ def _unpack(dev, recv, world, slot_groups, pass_slots, group_cap, list_cap):
         binds += [rhi.UAV(4 * s, o["records"]), rhi.UAV(4 * s + 1, o["masks"]), rhi.UAV(4 * s + 2, o["list"]), rhi.UAV(4 * s + 3, o["args"])]
     cl = dev.create_command_list()
     cl.open()
-    cl.dispatch("visibility_CS_UnpackShards", binds, (1, 1, 1), push=np.array([world, slot_groups], np.uint32))
+    cl.dispatch("visibility_CS_UnpackShards", binds, (1, 1, 1), push=np.array([world, slot_groups, R], np.uint32))
     cl.close()
     res = {}
     for _ in range(2):                                  # a recorded list is re-executed every other frame
@@ -87,42 +112,66 @@ def _unpack(dev, recv, world, slot_groups, pass_slots, group_cap, list_cap):
     return res
 
 
-def _random_local(rng, pass_slots, max_groups):
+def _run_records(rng, g):
+    """g records the way the instance pass emits them: per instance {id, lod, 0}, {id, lod, 32}, ... (1..40 groups; now
+    and then the same instance twice in a row, which must stay two runs)."""
+    rec = np.zeros((g, 3), np.uint32)
+    i = 0
+    inst = 0
+    while i < g:
+        n = min(int(rng.integers(1, 41)) if rng.random() < 0.3 else int(rng.integers(1, 6)), g - i)
+        inst = inst if rng.random() < 0.1 else int(rng.integers(0, 2 ** 32))
+        rec[i:i + n, 0], rec[i:i + n, 1], rec[i:i + n, 2] = inst, int(rng.integers(0, 8)), 32 * np.arange(n)
+        i += n
+    return rec
+
+
+def _random_local(rng, pass_slots, max_groups, runs=False):
     loc = {}
     for s in pass_slots:
         g = int(rng.integers(0, max_groups + 1))
-        rec = rng.integers(0, 2 ** 32, (g, 3), dtype=np.uint64).astype(np.uint32)
+        rec = _run_records(rng, g) if runs else rng.integers(0, 2 ** 32, (g, 3), dtype=np.uint64).astype(np.uint32)
         m = rng.integers(0, 2 ** 32, g, dtype=np.uint64).astype(np.uint32)
         m[rng.random(g) < 0.3] = 0
         loc[s] = (rec, m, int(np.unpackbits(m.view(np.uint8)).sum()))
     return loc
 
 
-@pytest.mark.parametrize("world,pass_slots,max_groups", [(1, (0, 1), 300), (3, (0, 1), 2000), (8, (0, 1, 2, 3), 700), (64, (0,), 40), (2, (1, 3), 100000)])
-def test_pack_unpack_kernels_equal_numpy_protocol(dev, world, pass_slots, max_groups):
+@pytest.mark.parametrize("world,pass_slots,max_groups,runs", [(1, (0, 1), 300, False), (3, (0, 1), 2000, True), (8, (0, 1, 2, 3), 700, True), (64, (0,), 40, False),
+                                                              (2, (1, 3), 100000, False), (2, (0, 1), 150000, True)])
+def test_pack_unpack_kernels_equal_numpy_protocol(dev, world, pass_slots, max_groups, runs):
+    """runs False: random record words (every record its own run: the encoding must stay lossless); True: records the way
+    the instance pass emits them, with a run capacity below the group capacity."""
+    from exchange_ref import runs_of_records_np
     rng = np.random.default_rng(world * 1000 + len(pass_slots))
     S = max_groups * len(pass_slots) + 3
-    locals_ = [_random_local(rng, pass_slots, max_groups) for _ in range(world)]
+    locals_ = [_random_local(rng, pass_slots, max_groups, runs) for _ in range(world)]
     if world > 1:
         locals_[1] = {s: (np.zeros((0, 3), np.uint32), np.zeros(0, np.uint32), 0) for s in pass_slots}    # an empty rank
+    R = max(sum(len(runs_of_records_np(v[0])) for v in loc.values()) for loc in locals_) + 1 if runs else S
+    assert not runs or R < 0.6 * S
     slots = []
-    for loc in locals_:
-        got = _pack(dev, loc, S)
-        ref = pack_shard_np(loc, S)
+    H = gather.HEADER_WORDS
+    state, _ = _pack_state(dev, S)                       # ONE state buffer for all packs, each executed an odd number of times
+    for k, loc in enumerate(locals_):
+        got = _pack(dev, loc, S, slot_runs=R, repeat=1 + 2 * (k % 2), state=state)
+        ref = pack_shard_np(loc, S, R)
         used = sum(len(v[0]) for v in loc.values())
-        H = gather.HEADER_WORDS
+        used_runs = int(ref[13])
         assert np.array_equal(got[:H], ref[:H])
-        assert np.array_equal(got[H:H + 3 * used], ref[H:H + 3 * used]) and np.array_equal(got[H + 3 * S:H + 3 * S + used], ref[H + 3 * S:H + 3 * S + used])
-        assert np.all(got[H + 3 * used:H + 3 * S] == 0xDEADBEEF), "pack wrote past the packed records"
+        assert np.array_equal(got[H:H + 4 * used_runs], ref[H:H + 4 * used_runs]) and np.array_equal(got[H + 4 * R:H + 4 * R + used], ref[H + 4 * R:H + 4 * R + used])
+        assert np.all(got[H + 4 * used_runs:H + 4 * R] == 0xDEADBEEF), "pack wrote past the packed runs"
         slots.append(got)
+    state.release()
     recv = np.concatenate(slots)
     cap = world * S
-    got = _unpack(dev, recv, world, S, pass_slots, cap, 32 * cap)
-    ref = unpack_shards_np(recv, world, S, pass_slots, cap)
+    got = _unpack(dev, recv, world, S, pass_slots, cap, 32 * cap, slot_runs=R)
+    ref = unpack_shards_np(recv, world, S, pass_slots, cap, R)
     for s in pass_slots:
         assert got[s]["status"] == 0 and ref[s]["status"] == 0
         assert got[s]["G"] == ref[s]["G"] and got[s]["V"] == ref[s]["V"]
         assert list(got[s]["args"][:7]) == [ref[s]["G"], 1, 1, ref[s]["G"], ref[s]["V"], 1, 1]
+        assert np.array_equal(ref[s]["records"], np.concatenate([np.asarray(loc[s][0], np.uint32).reshape(-1, 3) for loc in locals_])), "the run encoding is lossless"
         assert np.array_equal(got[s]["records"], ref[s]["records"])
         assert np.array_equal(got[s]["masks"], ref[s]["masks"])
         assert np.array_equal(got[s]["list"], ref[s]["list"])
@@ -132,7 +181,7 @@ def test_overflow_is_flagged_not_silent(dev):
     S = 40
     big = {0: (np.arange(90, dtype=np.uint32).reshape(30, 3), np.ones(30, np.uint32), 30), 1: (np.arange(60, dtype=np.uint32).reshape(20, 3), np.full(20, 3, np.uint32), 40)}
     got = _pack(dev, big, S)
-    assert np.array_equal(got, pack_shard_np(big, S)) or (got[8] == 1 and got[0] == 30 and got[2] == 10)
+    assert _same_used_words(got, pack_shard_np(big, S), S, S) and got[8] == 1 and got[0] == 30 and got[2] == 10
     res = _unpack(dev, got, 1, S, (0, 1), S, 32 * S)
     assert res[0]["status"] & gather.STATUS_SLOT_OVERFLOW and res[1]["status"] & gather.STATUS_SLOT_OVERFLOW
     assert res[0]["G"] == 30 and res[1]["G"] == 10
@@ -145,9 +194,14 @@ def test_overflow_is_flagged_not_silent(dev):
     # a rank that dropped groups at its own capacity (Q2): the sharded result is not the single-GPU one -> flagged
     q2 = {0: (np.arange(90, dtype=np.uint32).reshape(30, 3), np.ones(30, np.uint32), 30, 37)}
     sl = _pack(dev, q2, S)
-    H = gather.HEADER_WORDS
-    assert np.array_equal(sl[:H + 90], pack_shard_np(q2, S)[:H + 90]) and sl[9] == 1
+    assert _same_used_words(sl, pack_shard_np(q2, S), S, S) and sl[9] == 1
     assert _unpack(dev, sl, 1, S, (0,), S, 32 * S)[0]["status"] == gather.STATUS_GROUPS_DROPPED
+    # more runs than the slot's run capacity: flagged, nothing written past the run array
+    many = {0: (np.arange(90, dtype=np.uint32).reshape(30, 3), np.ones(30, np.uint32), 30)}
+    sl = _pack(dev, many, S, slot_runs=12)
+    ref = pack_shard_np(many, S, 12)
+    assert sl[8] == 1 and _same_used_words(sl, ref, S, 12) and sl[10] == 30
+    assert _unpack(dev, sl, 1, S, (0,), S, 32 * S, slot_runs=12)[0]["status"] & (gather.STATUS_SLOT_OVERFLOW | gather.STATUS_BAD_HEADER)
 
 
 @pytest.mark.parametrize("world", [2, 5])
@@ -169,6 +223,8 @@ def test_sharded_frames_gather_to_the_single_gpu_result(dev, oracle, world):
     md, inst = scene.meshData, scene.instances
     caps = [gather.shard_group_capacity(md["m_MeshLODDatas"]["m_NumMeshlets"], inst["m_MeshDataIdx"][scene.opaqueIds[slice(*gather.shard_range(len(scene.opaqueIds), p, world))]]) for p in range(world)]
     S = max(caps)
+    R = max(gather.shard_run_capacity(b - a) for a, b in (gather.shard_range(len(scene.opaqueIds), p, world) for p in range(world)))
+    assert R < S / 2
     from toyrenderer_amd import rhi
     assert full.lateCount[0] > 64, "the late list must be long enough for the dispatch-size rule (Q1) to truncate it"
     L = rhi.load()
@@ -193,24 +249,26 @@ def test_sharded_frames_gather_to_the_single_gpu_result(dev, oracle, world):
             if phase == "count":
                 late_counts[p] = drv.results()["lateCount"]
             else:
-                slot = dev.create_buffer(4 * gather.slot_words(S), "slot")
-                binds = [rhi.PUSH(0), rhi.UAV(0, slot)]
+                slot = dev.create_buffer(4 * gather.slot_words(S, R), "slot")
+                state, _ = _pack_state(dev, S)
+                binds = [rhi.PUSH(0), rhi.UAV(0, slot), rhi.UAV(1, state)]
                 for s in (0, 1):
                     binds += [rhi.SRV(4 * s, drv.records[s]), rhi.SRV(4 * s + 1, drv.visMask[s]), rhi.SRV(4 * s + 2, drv.dispatchArgs[s]), rhi.SRV(4 * s + 3, drv.drawArgs[s])]
                 cl = dev.create_command_list()
                 cl.open()
-                cl.dispatch("visibility_CS_PackShard", binds, (1, 1, 1), push=np.array([S], np.uint32))
+                cl.dispatch("visibility_CS_PackShard", binds, (1, 1, 1), push=np.array([S, R], np.uint32))
                 cl.close()
                 dev.execute(cl)
                 dev.wait_idle()
-                slots.append(slot.download(np.uint32, gather.slot_words(S)))
+                slots.append(slot.download(np.uint32, gather.slot_words(S, R)))
                 assert slots[-1][8] == 0 and slots[-1][9] == 0 and slots[-1][0] + slots[-1][2] <= caps[p]
-                cl.release(); slot.release()
+                assert slots[-1][11] <= i1 - i0, "one run per submitted instance"
+                cl.release(); slot.release(); state.release()
             drv.release(); gs.release()
     counts_buf.release()
     assert int(late_counts.sum()) == int(full.lateCount[0]), "shards' late lists must partition the full late list"
     gcap = sum(caps)
-    res = _unpack(dev, np.concatenate(slots), world, S, (0, 1), gcap, 32 * gcap)
+    res = _unpack(dev, np.concatenate(slots), world, S, (0, 1), gcap, 32 * gcap, slot_runs=R)
     for s in (0, 1):
         assert res[s]["status"] == 0
         assert np.array_equal(res[s]["records"], full.records[s].view(np.uint32).reshape(-1, 3)), f"slot {s}: records"

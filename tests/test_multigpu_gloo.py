@@ -131,3 +131,31 @@ def test_slot_protocol_numpy_roundtrip_and_overflow():
     assert unpack_shards_np(sl, 1, S, (0, 1), S)[0]["status"] & 1
     # whole-scene capacity too small
     assert unpack_shards_np(np.concatenate(slots), world, S, (0, 1, 3), 5)[0]["status"] & 2
+
+
+def test_run_encoding_is_lossless_and_one_entry_per_instance():
+    """The records travel as runs (gather.py): {instance, lod, first offset, first record} per maximal run of records that
+    continue each other.  Round trip on records the way the instance pass emits them, on adversarial ones, and through a
+    slot whose run capacity is far below its group capacity."""
+    from exchange_ref import pack_shard_np, records_of_runs_np, runs_of_records_np, unpack_shards_np
+    from toyrenderer_amd.gather import slot_words
+    rng = np.random.default_rng(11)
+    groups = rng.integers(1, 9, 500)
+    rec = np.concatenate([np.stack([np.full(g, i, np.uint32), np.full(g, i % 5, np.uint32), 32 * np.arange(g, dtype=np.uint32)], 1) for i, g in enumerate(groups)])
+    runs = runs_of_records_np(rec)
+    assert len(runs) == 500 and np.array_equal(runs[:, 3], np.concatenate([[0], np.cumsum(groups)[:-1]]))
+    assert np.array_equal(records_of_runs_np(runs, len(rec)), rec)
+    # the same instance twice in a row stays two runs; offsets that do not start at 0 or wrap around 2^32 survive
+    odd = np.array([[7, 1, 0], [7, 1, 32], [7, 1, 0], [7, 2, 32], [9, 2, 0xFFFFFFF0], [9, 2, 0x10], [9, 2, 0x30]], np.uint32)
+    r = runs_of_records_np(odd)
+    assert r[:, 3].tolist() == [0, 2, 3, 4] and np.array_equal(records_of_runs_np(r, len(odd)), odd)
+    S, R = len(rec) + 10, 520
+    m = rng.integers(0, 2 ** 32, len(rec), dtype=np.uint64).astype(np.uint32)
+    half = int(np.cumsum(groups)[249])
+    loc = {0: (rec[:half], m[:half], 0), 1: (rec[half:], m[half:], 0)}
+    sl = pack_shard_np(loc, S, R)
+    assert len(sl) == slot_words(S, R) < slot_words(S) / 2 and sl[8] == 0 and sl[10] == 250 and sl[11] == sl[13] == 500
+    out = unpack_shards_np(np.concatenate([sl, sl]), 2, S, (0, 1), 2 * S, R)
+    assert np.array_equal(out[0]["records"], np.concatenate([rec[:half]] * 2)) and np.array_equal(out[1]["records"], np.concatenate([rec[half:]] * 2))
+    assert out[0]["status"] == 0
+    assert pack_shard_np(loc, S, 499)[8] == 1 and unpack_shards_np(pack_shard_np(loc, S, 499), 1, S, (0, 1), S, 499)[0]["status"] != 0

@@ -1,5 +1,5 @@
 // ShardExchange.cpp -- native per-frame driver of the multi-GPU exchange (not in the reference: single GPU,
-// GraphicRHI.cpp:165).  Protocol, slot layout and rationale: toyrenderer_amd/gather.py (the Python statement of the
+// GraphicRHI.cpp:165).  Protocol, slot layout (header, run entries, lane masks) and rationale: toyrenderer_amd/gather.py (the Python statement of the
 // same thing, kept for tests) and DESIGN.md section 6.  Everything a frame needs is done here without leaving native
 // code: pack (compute stream) -> one all-gather -> unpack + list rebuild (exchange stream), double-buffered and
 // ordered by events; and the in-frame late-count exchange (phase 0 after the early instance cull on an auxiliary
@@ -38,6 +38,8 @@ struct Exchange
     void* packed[2] = {}, *released[2] = {};        // events
     void* latePosted[2] = {}, *lateReady[2] = {};
     trhip_buffer send[2] = {}, recv[2] = {};
+    trhip_buffer packState = nullptr;               // the pack kernel's ticket / status words (it leaves them zero)
+    uint32_t slotRuns = 0;
     trhip_buffer sendOnCompute[2] = {};              // the same memory, wrapped for the compute device's lists
     trhip_buffer lateCounts[2] = {};                 // gathered late counts per bucket (world words)
     trhip_buffer records[kMaxPassSlots] = {}, masks[kMaxPassSlots] = {}, list[kMaxPassSlots] = {}, args[kMaxPassSlots] = {};
@@ -95,7 +97,7 @@ void recordUnpack(Exchange& x, int b)
             binds.push_back(bind(TRHIP_BIND_STRUCTURED_UAV, 4 * s + 2, x.list[s]));
             binds.push_back(bind(TRHIP_BIND_STRUCTURED_UAV, 4 * s + 3, x.args[s]));
         }
-    const uint32_t push[2] = { x.desc.world, x.desc.slot_groups };
+    const uint32_t push[3] = { x.desc.world, x.desc.slot_groups, x.slotRuns };
     require(trhip_cmd_open(x.unpackList[b]), "exchange: open unpack list");
     require(trhip_cmd_dispatch(x.unpackList[b], "visibility_CS_UnpackShards", binds.data(), (uint32_t)binds.size(), push, sizeof push, 1, 1, 1),
             "exchange: record visibility_CS_UnpackShards");
@@ -119,10 +121,11 @@ void recordPackIfNeeded(Exchange& x, int b)
     std::vector<trhip_binding> binds;
     binds.push_back(bind(TRHIP_BIND_PUSH_CONSTANTS, 0, nullptr));
     binds.push_back(bind(TRHIP_BIND_STRUCTURED_UAV, 0, x.sendOnCompute[b]));
+    binds.push_back(bind(TRHIP_BIND_STRUCTURED_UAV, 1, x.packState));
     for (uint32_t s = 0; s < kMaxPassSlots; ++s)
         if (key[s][0])
             for (uint32_t k = 0; k < 4; ++k) binds.push_back(bind(TRHIP_BIND_STRUCTURED_SRV, 4 * s + k, key[s][k]));
-    const uint32_t push[1] = { x.desc.slot_groups };
+    const uint32_t push[2] = { x.desc.slot_groups, x.slotRuns };
     require(trhip_cmd_open(x.packList[b]), "exchange: open pack list");
     require(trhip_cmd_dispatch(x.packList[b], "visibility_CS_PackShard", binds.data(), (uint32_t)binds.size(), push, sizeof push, 1, 1, 1),
             "exchange: record visibility_CS_PackShard");
@@ -172,6 +175,7 @@ void destroy()
     for (uint32_t s = 0; s < kMaxPassSlots; ++s)
         for (trhip_buffer buf : { x.records[s], x.masks[s], x.list[s], x.args[s] })
             if (buf) trhip_buffer_release(buf);
+    if (x.packState) trhip_buffer_release(x.packState);
     if (x.commDev) trhip_device_destroy(x.commDev);
     trhip_stream_destroy(x.commStream);
     trhip_stream_destroy(x.auxStream);
@@ -184,11 +188,13 @@ void ShardExchangeCreate(const trhost_exchange_desc& d)
 {
     destroy();
     check(d.world >= 1 && d.rank < d.world && d.slots_allgather && d.late_allgather && d.pass_slot_mask != 0 && d.pass_slot_mask < 16);
-    check((uint64_t)d.world * (kHeaderWords + 4ull * d.slot_groups) < (1ull << 32));
+    const uint32_t slotRuns = d.slot_runs ? d.slot_runs : d.slot_groups;
+    check((uint64_t)d.world * (kHeaderWords + 4ull * slotRuns + d.slot_groups) < (1ull << 32));
     g_Exchange = std::make_unique<Exchange>();
     Exchange& x = *g_Exchange;
     x.desc = d;
-    x.slotWords = kHeaderWords + 4u * d.slot_groups;
+    x.slotRuns = slotRuns;
+    x.slotWords = kHeaderWords + 4u * slotRuns + d.slot_groups;
     x.compute = g_Graphic.m_NVRHIDevice->native();
     x.deviceIndex = g_Graphic.m_DeviceIndex;
     // the late-count exchange is tiny and the frame waits for it: highest priority; the slot exchange is background work
@@ -222,6 +228,12 @@ void ShardExchangeCreate(const trhost_exchange_desc& d)
             x.list[s] = makeBuffer(x.commDev, 4ull * listCap, "AllVisibleList");
             x.args[s] = makeBuffer(x.commDev, 32, "AllArgs");
         }
+    {   // visibility_CS_PackShard's state words (two halves): zero once, every launch zeroes the half the next one uses
+        const uint64_t words = 2ull * (d.slot_groups / 1024u + kMaxPassSlots + 1u);
+        x.packState = makeBuffer(x.compute, 8ull * words, "ShardPackState");
+        std::vector<uint64_t> zero(words, 0);
+        require(trhip_buffer_upload(x.packState, 0, zero.data(), 8ull * words), "exchange: zero the pack state");
+    }
     for (int b = 0; b < 2; ++b) recordUnpack(x, b);
     SetShardLateExchange(&lateHook, &x, d.list_presence_mask, d.depth_allreduce_max, d.depth_user);
 }

@@ -41,6 +41,11 @@
 __device__ unsigned long long g_stampSums[8];
 #define g_pathCount (g_stampSums + 4)          // [4] steps on the fast arithmetic path, [5] on the exact path (TR_COUNT_PATHS)
 #endif
+#include <atomic>
+#include <memory>
+#include <mutex>
+#include <unordered_map>
+
 #include "cull_math.hip.h"
 #include "instance_cache.hip.h"
 #include "trhip_internal.h"
@@ -664,21 +669,32 @@ __global__ __launch_bounds__(kCompactThreads) void visCompactKernel(MeshletCullA
 
 // ---------------------------------------------------------------------------------------------
 // Multi-GPU exchange (not in the reference: single GPU, GraphicRHI.cpp:165).
-// A rank ships its pass slots in COMPACT form -- the 12-byte record and the 4-byte lane mask of every
-// group, i.e. 1 bit per tested meshlet instead of 4 bytes per visible meshlet -- inside one
-// fixed-capacity "shard slot", so that the frame needs ONE equal-size all-gather and no host
-// read-back.  Every rank then concatenates the slots rank-major (device-side offsets from the slot
-// headers) and rebuilds the whole-scene ordered visible list with the same count/scan/expand kernels
-// the single-GPU path uses: the result is bit-identical to a single-GPU frame.
+// A rank ships its pass slots in COMPACT form inside one fixed-capacity "shard slot", so that the frame needs ONE
+// equal-size all-gather and no host read-back:
+//   * the amplification records as RUNS.  The instance pass emits, per submitted instance, consecutive records
+//     {instance, lod, 0}, {instance, lod, 32}, {instance, lod, 64}, ... (gpuculling.hlsl:139-157), so a maximal run of
+//     records that continue each other (same instance, same lod, group offset + 32) is described by 16 bytes --
+//     {instance, lod, first group offset, index of its first record in the pass slot} -- whatever its length: one entry
+//     per submitted INSTANCE instead of 12 bytes per GROUP.  The encoding is lossless for any record array (a record
+//     that continues nothing starts a run of its own);
+//   * the lane mask of every group (4 bytes: 1 bit per tested meshlet instead of 4 bytes per visible meshlet).
+// Every rank then rebuilds the whole-scene records rank-major straight from the received run entries (device-side
+// offsets from the slot headers), concatenates the masks and rebuilds the ordered visible list with the same
+// count/scan/expand kernels the single-GPU path uses: the result is bit-identical to a single-GPU frame.
 //
-// Shard slot (u32 words), S = slotGroups:
-//   [0..15]        header: {G_s, V_s} for pass slot s = 0..3 at words 2s, 2s+1; word 8 = overflow flag,
-//                  word 9 = the rank dropped groups at its record capacity (Q2)
-//   [16, 16+3S)    records of pass slot 0, then 1, ... back to back (3 words each)
-//   [16+3S, 16+4S) lane masks in the same order
+// Shard slot (u32 words), S = slotGroups, R = slotRuns:
+//   [0..15]         header: {G_s, V_s} for pass slot s = 0..3 at words 2s, 2s+1; word 8 = overflow flag (groups > S or
+//                   runs > R), word 9 = the rank dropped groups at its record capacity (Q2), words 10..13 = runs of
+//                   pass slots 0..s (cumulative end of pass slot s in the run array)
+//   [16, 16+4R)     run entries of pass slot 0, then 1, ... back to back (4 words each)
+//   [16+4R, +S)     lane masks of pass slot 0, then 1, ... back to back
 constexpr uint32_t kMaxPassSlots = 4;
 constexpr uint32_t kSlotHeaderWords = 16;
 constexpr uint32_t kMaxRanks = 64;
+constexpr uint32_t kPackThreads = 256;
+constexpr uint32_t kPackRounds = 4;                                   // records per thread and tile: all loads of a tile in flight at once
+constexpr uint32_t kPackTile = kPackThreads * kPackRounds;            // 1024 records
+constexpr unsigned long long kPackFlag = 1ull << 63, kPackPoison = 1ull << 40;
 
 struct ShardPackArgs
 {
@@ -689,14 +705,29 @@ struct ShardPackArgs
     uint32_t argsWords[kMaxPassSlots];
     uint32_t recordCapacity[kMaxPassSlots];
     uint32_t* slot;
-    uint32_t slotGroups;
+    uint32_t slotGroups, slotRuns;
+    unsigned long long* status;            // status word of tile t; all zero when the launch starts
+    unsigned long long* statusNext;        // the other half of the state buffer: zeroed by this launch for the next one
+    uint32_t maxTiles;
+    uint32_t tileBlocks;                   // workgroups [0, tileBlocks) compact the runs, the rest copy the masks
 };
 
-__global__ __launch_bounds__(256) void shardPackKernel(ShardPackArgs a)
+// The run starts of all pass slots are compacted in order by tiles of 1024 records: a tile publishes its number of run
+// starts and sums those of ALL its predecessors.  Tile t belongs to workgroup t mod tileBlocks, and the host keeps the
+// grid within what the chip holds at once (<= 4 workgroups of 256 threads per CU), so every tile a workgroup waits for
+// is held by a workgroup that is running or has finished -- no tickets: a same-address atomic per workgroup is what
+// the first version of this kernel spent most of its 20 us on.  The other workgroups copy the masks meanwhile.
+// The status words live in one half of the state buffer; every launch zeroes the OTHER half, which the next launch on
+// that buffer uses (the host alternates per launch, recordPackShard), so the recorded command is re-executed frame
+// after frame without a clear launch in front of it and without a last-one-out counter.
+__global__ __launch_bounds__(kPackThreads) void shardPackKernel(ShardPackArgs a)
 {
-    uint32_t G[kMaxPassSlots], start[kMaxPassSlots + 1];
+    __shared__ uint32_t s_cnt[kPackRounds * (kPackThreads / 64)];
+    __shared__ uint32_t s_total;
+    __shared__ unsigned long long s_pre[kPackThreads / 64][kMaxPassSlots + 1];
+    uint32_t G[kMaxPassSlots], start[kMaxPassSlots + 1], tileStart[kMaxPassSlots + 1];
     uint32_t overflow = 0, dropped = 0;
-    start[0] = 0;
+    start[0] = 0; tileStart[0] = 0;
 #pragma unroll
     for (uint32_t s = 0; s < kMaxPassSlots; ++s) {
         uint32_t g = 0;
@@ -709,82 +740,193 @@ __global__ __launch_bounds__(256) void shardPackKernel(ShardPackArgs a)
         if (start[s] + g > a.slotGroups) { g = a.slotGroups - start[s]; overflow = 1; }
         G[s] = g;
         start[s + 1] = start[s] + g;
+        tileStart[s + 1] = tileStart[s] + (g + kPackTile - 1u) / kPackTile;
     }
-    const uint32_t total = start[kMaxPassSlots];
-    uint32_t* recOut = a.slot + kSlotHeaderWords;
-    uint32_t* maskOut = recOut + 3ull * a.slotGroups;
-    const uint32_t stride = gridDim.x * 256u;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < 3u * total; i += stride) {   // records, word by word (coalesced)
-        const uint32_t g = i / 3u;
+    const uint32_t total = start[kMaxPassSlots], numTiles = tileStart[kMaxPassSlots];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t* runOut = a.slot + kSlotHeaderWords;
+    uint32_t* maskOut = runOut + 4ull * a.slotRuns;
+    unsigned long long* status = a.status;
+    if (blockIdx.x < a.tileBlocks)
+        for (uint32_t j = blockIdx.x * kPackThreads + tid; j < a.maxTiles; j += a.tileBlocks * kPackThreads) a.statusNext[j] = 0ull;
+    const uint32_t tilesToDo = numTiles ? numTiles : 1u;                              // an empty shard still writes its header
+    for (uint32_t tile = blockIdx.x; blockIdx.x < a.tileBlocks && tile < tilesToDo; tile += a.tileBlocks) {
+        __syncthreads();
         uint32_t s = 0;
 #pragma unroll
-        for (uint32_t q = 1; q < kMaxPassSlots; ++q) s += g >= start[q] ? 1u : 0u;
-        recOut[i] = a.records[s][i - 3u * start[s]];
+        for (uint32_t q = 1; q < kMaxPassSlots; ++q) s += tile >= tileStart[q] && numTiles ? 1u : 0u;
+        const uint32_t Gs = numTiles ? G[s] : 0u;
+        const uint32_t* rec = a.records[s];
+        const uint32_t g0 = (tile - tileStart[s]) * kPackTile;
+        // ---- which records of the tile start a run (round i looks at records g0 + 256 i + tid: coalesced) -------------
+        uint32_t bits = 0;
+        uint32_t cur[kPackRounds][3], prev[kPackRounds][3];
+#pragma unroll
+        for (uint32_t i = 0; i < kPackRounds; ++i) {
+            const uint32_t g = g0 + i * kPackThreads + tid;
+#pragma unroll
+            for (uint32_t w = 0; w < 3; ++w) {
+                cur[i][w] = g < Gs ? rec[3ull * g + w] : 0u;
+                prev[i][w] = g < Gs && g > 0u ? rec[3ull * g + w - 3u] : 0u;
+            }
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < kPackRounds; ++i) {
+            const uint32_t g = g0 + i * kPackThreads + tid;
+            const bool st = g < Gs && (g == 0u || !(cur[i][0] == prev[i][0] && cur[i][1] == prev[i][1] && cur[i][2] == prev[i][2] + 32u));
+            const unsigned long long b = __ballot(st);
+            if (lane == 0) s_cnt[i * (kPackThreads / 64) + wave] = (uint32_t)__popcll(b);
+            bits |= st ? 1u << i : 0u;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            constexpr uint32_t kCounters = kPackRounds * (kPackThreads / 64);
+            const uint32_t c = lane < kCounters ? s_cnt[lane] : 0u;
+            const uint32_t inc = waveInclusiveScan(c, lane);
+            if (lane < kCounters) s_cnt[lane] = inc - c;
+            if (lane == 63) s_total = inc;
+        }
+        __syncthreads();
+        const uint32_t tileRuns = s_total;
+        if (tid == 0 && numTiles) __hip_atomic_store(&status[tile], kPackFlag | (unsigned long long)tileRuns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- run starts before this tile; the LAST tile also needs them per pass slot (header words 10..13) ------------
+        const bool last = numTiles == 0u || tile == numTiles - 1u;
+        unsigned long long sum = 0, part[kMaxPassSlots] = {};
+        for (uint32_t j = tid; j < tile; j += kPackThreads) {
+            unsigned long long v = 0;
+            uint32_t spins = 0;
+            for (;;) {
+                v = __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v & kPackFlag) { v &= ~kPackFlag; break; }
+                if (++spins > (1u << 22)) { v = kPackPoison; break; }               // never seen; a hang would take the GPU down
+            }
+            sum += v;
+            if (last) {
+#pragma unroll
+                for (uint32_t q = 0; q < kMaxPassSlots; ++q) part[q] += j < tileStart[q + 1] ? v : 0ull;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+        if (last) {
+#pragma unroll
+            for (uint32_t q = 0; q < kMaxPassSlots; ++q) {
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) part[q] += __shfl_xor(part[q], d);
+            }
+        }
+        if (lane == 0) {
+            s_pre[wave][0] = sum;
+            if (last) {
+#pragma unroll
+                for (uint32_t q = 0; q < kMaxPassSlots; ++q) s_pre[wave][q + 1] = part[q];
+            }
+        }
+        __syncthreads();
+        unsigned long long prefix = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kPackThreads / 64; ++w) prefix += s_pre[w][0];
+        const bool poisoned = (prefix >> 40) != 0ull;
+        // ---- the tile's run entries ----------------------------------------------------------------------------------
+#pragma unroll
+        for (uint32_t i = 0; i < kPackRounds; ++i) {
+            const bool st = (bits >> i) & 1u;
+            const unsigned long long b = __ballot(st);
+            if (st) {
+                const unsigned long long idx = prefix + s_cnt[i * (kPackThreads / 64) + wave] + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+                if (idx < a.slotRuns && !poisoned)
+                    *reinterpret_cast<uint4*>(runOut + 4ull * idx) = make_uint4(cur[i][0], cur[i][1], cur[i][2], g0 + i * kPackThreads + tid);
+            }
+        }
+        // ---- header (the last tile knows every count) -------------------------------------------------------------------
+        if (last && tid < kSlotHeaderWords) {
+            unsigned long long end[kMaxPassSlots];
+#pragma unroll
+            for (uint32_t q = 0; q < kMaxPassSlots; ++q) {
+                end[q] = 0;
+#pragma unroll
+                for (uint32_t w = 0; w < kPackThreads / 64; ++w) end[q] += s_pre[w][q + 1];
+                if (numTiles && tile < tileStart[q + 1]) end[q] += tileRuns;          // this tile belongs to pass slot <= q
+            }
+            const unsigned long long allRuns = prefix + tileRuns;
+            uint32_t v = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < kMaxPassSlots; ++q) {
+                if (tid == 2 * q) v = G[q];
+                if (tid == 2 * q + 1) v = a.drawArgs[q] ? a.drawArgs[q][0] : 0u;
+                if (tid == 10 + q) v = poisoned ? 0xFFFFFFFFu : (uint32_t)end[q];
+            }
+            if (tid == 8) v = (overflow || allRuns > a.slotRuns || poisoned) ? 1u : 0u;
+            if (tid == 9) v = dropped;
+            a.slot[tid] = v;
+        }
     }
-    for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < total; g += stride) {
+    for (uint32_t g = (blockIdx.x - a.tileBlocks) * kPackThreads + tid; blockIdx.x >= a.tileBlocks && g < total; g += (gridDim.x - a.tileBlocks) * kPackThreads) {   // masks
         uint32_t s = 0;
 #pragma unroll
         for (uint32_t q = 1; q < kMaxPassSlots; ++q) s += g >= start[q] ? 1u : 0u;
         maskOut[g] = a.masks[s][g - start[s]];
     }
-    if (blockIdx.x == 0 && threadIdx.x < kSlotHeaderWords) {
-        uint32_t v = 0;
-#pragma unroll
-        for (uint32_t s = 0; s < kMaxPassSlots; ++s) {
-            if (threadIdx.x == 2 * s) v = G[s];
-            if (threadIdx.x == 2 * s + 1) v = a.drawArgs[s] ? a.drawArgs[s][0] : 0u;
-        }
-        if (threadIdx.x == 8) v = overflow;
-        if (threadIdx.x == 9) v = dropped;
-        a.slot[threadIdx.x] = v;
-    }
 }
 
 struct ShardUnpackArgs
 {
-    const uint32_t* recv;                  // world x (16 + 4 * slotGroups) words
-    uint32_t world, slotGroups;
+    const uint32_t* recv;                  // world x (16 + 4 * slotRuns + slotGroups) words
+    uint32_t world, slotGroups, slotRuns;
     uint32_t* records[kMaxPassSlots];      // whole-scene outputs per pass slot (nullptr = not gathered)
     uint32_t* masks[kMaxPassSlots];
     uint32_t* args[kMaxPassSlots];         // 8 words: {G,1,1,G} dispatch args, {V,1,1} draw args, status
     uint32_t capacity[kMaxPassSlots];      // groups
 };
 
-// Rank-major concatenation.  Segment k = (rank p, pass slot s, records | masks); every block derives the
-// segment table from the slot headers (world <= 64), then the grid copies the words of all segments.
-__global__ __launch_bounds__(256) void shardConcatKernel(ShardUnpackArgs a)
+// Rank-major rebuild.  Segment k = (rank p, pass slot s); every block derives the segment table from the slot headers
+// (world <= 64): where the segment's masks and run entries lie in the received slot, where its groups go in the
+// whole-scene arrays.  The grid then copies the mask words of all segments and expands the run entries of all segments
+// (one thread per run; a run longer than 8 records is written by the whole wave).
+__global__ __launch_bounds__(256) void shardUnpackKernel(ShardUnpackArgs a)
 {
+    constexpr uint32_t kSeg = kMaxPassSlots * kMaxRanks;
     __shared__ uint32_t s_G[kMaxRanks][kMaxPassSlots];
-    __shared__ uint32_t s_start[2 * kMaxPassSlots * kMaxRanks + 1];
-    __shared__ uint32_t s_src[2 * kMaxPassSlots * kMaxRanks];
-    __shared__ uint32_t s_dst[2 * kMaxPassSlots * kMaxRanks];
-    const uint32_t slotWords = kSlotHeaderWords + 4u * a.slotGroups;
-    const uint32_t tid = threadIdx.x;
+    __shared__ uint32_t s_E[kMaxRanks][kMaxPassSlots];
+    __shared__ uint32_t s_maskStart[kSeg + 1], s_runStart[kSeg + 1];
+    __shared__ uint32_t s_maskSrc[kSeg], s_runSrc[kSeg], s_dst[kSeg], s_len[kSeg];
+    const uint32_t slotWords = kSlotHeaderWords + 4u * a.slotRuns + a.slotGroups;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
     if (tid < a.world * kMaxPassSlots) {
         const uint32_t p = tid / kMaxPassSlots, s = tid % kMaxPassSlots;
         s_G[p][s] = a.records[s] ? a.recv[(uint64_t)p * slotWords + 2u * s] : 0u;
+        s_E[p][s] = a.recv[(uint64_t)p * slotWords + 10u + s];
     }
     __syncthreads();
     if (tid == 0) {
-        uint32_t status = 0, run = 0, k = 0;
+        uint32_t status = 0, maskRun = 0, runRun = 0, k = 0;
         uint32_t off[kMaxPassSlots] = {};
         for (uint32_t p = 0; p < a.world; ++p) {
             if (a.recv[(uint64_t)p * slotWords + 8u]) status |= 1u;                // that rank's slot overflowed
             if (a.recv[(uint64_t)p * slotWords + 9u]) status |= 8u;                // that rank dropped groups (Q2)
-            uint32_t inSlot = 0;
+            uint32_t inSlot = 0, runBegin = 0;
+            bool bad = false;
             for (uint32_t s = 0; s < kMaxPassSlots; ++s) {
+                // a pass slot this rank did not gather still occupies its place in the sender's slot
+                const uint32_t sentG = a.recv[(uint64_t)p * slotWords + 2u * s];
                 uint32_t g = s_G[p][s];
                 const uint32_t srcG = inSlot;
-                inSlot += g;
-                if (inSlot > a.slotGroups) { status |= 4u; g = 0; }                // corrupt header: copy nothing
+                inSlot += sentG;
+                uint32_t runEnd = s_E[p][s];
+                if (inSlot > a.slotGroups || inSlot < sentG || runEnd < runBegin || runEnd > a.slotRuns) bad = true;   // corrupt header: copy nothing
+                if (bad) { status |= 4u; g = 0; runEnd = runBegin; }
+                uint32_t runs = a.records[s] ? runEnd - runBegin : 0u;
                 if (off[s] + g > a.capacity[s]) { g = a.capacity[s] - off[s]; status |= 2u; }
                 const uint32_t base = p * slotWords + kSlotHeaderWords;            // < 2^32 words (checked on the host)
-                s_start[k] = run; s_src[k] = base + 3u * srcG; s_dst[k] = 3u * off[s]; run += 3u * g; ++k;
-                s_start[k] = run; s_src[k] = base + 3u * a.slotGroups + srcG; s_dst[k] = off[s]; run += g; ++k;
+                s_maskStart[k] = maskRun; s_runStart[k] = runRun;
+                s_maskSrc[k] = base + 4u * a.slotRuns + srcG; s_runSrc[k] = base + 4u * runBegin;
+                s_dst[k] = off[s]; s_len[k] = g;
+                maskRun += g; runRun += runs; ++k;
                 off[s] += g;
+                runBegin = runEnd;
             }
         }
-        s_start[k] = run;
+        s_maskStart[k] = maskRun; s_runStart[k] = runRun;
         if (blockIdx.x == 0)
             for (uint32_t s = 0; s < kMaxPassSlots; ++s)
                 if (a.args[s]) {
@@ -793,17 +935,47 @@ __global__ __launch_bounds__(256) void shardConcatKernel(ShardUnpackArgs a)
                 }
     }
     __syncthreads();
-    const uint32_t numSeg = 2u * kMaxPassSlots * a.world;
-    const uint32_t total = s_start[numSeg];
-    for (uint32_t i = blockIdx.x * 256u + tid; i < total; i += gridDim.x * 256u) {
-        uint32_t lo = 0, hi = numSeg;                                              // last k with s_start[k] <= i
+    const uint32_t numSeg = kMaxPassSlots * a.world;
+    const uint32_t totalMasks = s_maskStart[numSeg];
+    for (uint32_t i = blockIdx.x * 256u + tid; i < totalMasks; i += gridDim.x * 256u) {
+        uint32_t lo = 0, hi = numSeg;                                              // last k with s_maskStart[k] <= i
         while (hi - lo > 1u) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (s_start[mid] <= i) lo = mid; else hi = mid;
+            if (s_maskStart[mid] <= i) lo = mid; else hi = mid;
         }
-        const uint32_t s = (lo >> 1) % kMaxPassSlots;
-        uint32_t* dst = (lo & 1u) ? a.masks[s] : a.records[s];
-        dst[s_dst[lo] + (i - s_start[lo])] = a.recv[(uint64_t)s_src[lo] + (i - s_start[lo])];
+        a.masks[lo % kMaxPassSlots][s_dst[lo] + (i - s_maskStart[lo])] = a.recv[(uint64_t)s_maskSrc[lo] + (i - s_maskStart[lo])];
+    }
+    const uint32_t totalRuns = s_runStart[numSeg];
+    for (uint32_t it = blockIdx.x * 256u + (tid & ~63u); it < totalRuns; it += gridDim.x * 256u) {    // wave-uniform bound
+        const uint32_t i = it + lane;
+        uint32_t id = 0, lod = 0, off0 = 0, first = 0, cnt = 0;
+        uint32_t* dst = nullptr;
+        if (i < totalRuns) {
+            uint32_t lo = 0, hi = numSeg;
+            while (hi - lo > 1u) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_runStart[mid] <= i) lo = mid; else hi = mid;
+            }
+            const uint32_t e = i - s_runStart[lo], runs = s_runStart[lo + 1] - s_runStart[lo], len = s_len[lo];
+            const uint4 entry = *reinterpret_cast<const uint4*>(a.recv + (uint64_t)s_runSrc[lo] + 4ull * e);
+            // the run ends where the next one of the same segment starts; the last one at the segment's group count.
+            // Clamped to the groups this segment may write (capacity), so nothing lands outside its range.
+            uint32_t next = e + 1u < runs ? a.recv[(uint64_t)s_runSrc[lo] + 4ull * (e + 1u) + 3u] : 0xFFFFFFFFu;
+            next = next < len ? next : len;
+            id = entry.x; lod = entry.y; off0 = entry.z; first = entry.w;
+            cnt = first < next ? next - first : 0u;
+            dst = a.records[lo % kMaxPassSlots] + 3ull * (s_dst[lo] + first);
+        }
+        if (cnt <= 8u)
+            for (uint32_t j = 0; j < cnt; ++j) { dst[3u * j] = id; dst[3u * j + 1u] = lod; dst[3u * j + 2u] = off0 + 32u * j; }
+        unsigned long long big = __ballot(cnt > 8u);
+        while (big) {
+            const int l = __builtin_ctzll(big);
+            big &= big - 1ull;
+            const uint32_t bid = __shfl(id, l), blod = __shfl(lod, l), boff = __shfl(off0, l), bcnt = __shfl(cnt, l);
+            uint32_t* bdst = (uint32_t*)(((unsigned long long)__shfl((uint32_t)((unsigned long long)dst >> 32), l) << 32) | __shfl((uint32_t)(unsigned long long)dst, l));
+            for (uint32_t j = lane; j < bcnt; j += 64u) { bdst[3u * j] = bid; bdst[3u * j + 1u] = blod; bdst[3u * j + 2u] = boff + 32u * j; }
+        }
     }
 }
 
@@ -980,17 +1152,27 @@ int recordASMain(trhip::DispatchCtx& ctx)
 }
 
 // "visibility_CS_PackShard": pass slot s binds t(4s) records, t(4s+1) visMask, t(4s+2) dispatch args,
-// t(4s+3) draw args (all four or none); u0 = the shard slot; push constants {slotGroups}.
+// t(4s+3) draw args (all four or none); u0 = the shard slot; u1 = the kernel's state words (16 bytes x
+// (slotGroups / 1024 + 5): two halves, ZERO before the first dispatch; launches on one state buffer must be ordered (one
+// stream): each uses one half and zeroes the other for the next); push constants {slotGroups, slotRuns}.
 int recordPackShard(trhip::DispatchCtx& ctx)
 {
-    const uint32_t* push = (const uint32_t*)ctx.constants(0, 4);
+    const uint32_t* push = (const uint32_t*)ctx.constants(0, 8);
     trhip_buffer_t* slot = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 0);
-    TRHIP_REQUIRE(push && slot, "%s: needs push constants {slotGroups} and UAV u0 (shard slot)", ctx.shaderName);
+    trhip_buffer_t* state = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 1);
+    TRHIP_REQUIRE(push && slot && state, "%s: needs push constants {slotGroups, slotRuns}, UAV u0 (shard slot) and UAV u1 (state words, zeroed once)", ctx.shaderName);
     ShardPackArgs a;
     memset(&a, 0, sizeof a);
     a.slotGroups = push[0];
-    TRHIP_REQUIRE(slot->byteSize >= ((uint64_t)kSlotHeaderWords + 4ull * a.slotGroups) * 4, "%s: shard slot buffer smaller than 16 + 4 * %u words", ctx.shaderName, a.slotGroups);
+    a.slotRuns = push[1];
+    const uint64_t slotWords = (uint64_t)kSlotHeaderWords + 4ull * a.slotRuns + a.slotGroups;
+    TRHIP_REQUIRE(slot->byteSize >= slotWords * 4, "%s: shard slot buffer smaller than 16 + 4 * %u + %u words", ctx.shaderName, a.slotRuns, a.slotGroups);
+    const uint64_t maxTiles = (uint64_t)a.slotGroups / kPackTile + kMaxPassSlots + 1u;       // every pass slot may end in a partial tile
+    TRHIP_REQUIRE(maxTiles < (1u << 30) && state->byteSize >= maxTiles * 16u, "%s: state buffer u1 smaller than %llu bytes", ctx.shaderName, (unsigned long long)(maxTiles * 16u));
+    TRHIP_REQUIRE(((uintptr_t)slot->ptr & 15u) == 0 && ((uintptr_t)state->ptr & 7u) == 0, "%s: u0 / u1 not 16 / 8-byte aligned", ctx.shaderName);
     a.slot = (uint32_t*)slot->ptr;
+    a.maxTiles = (uint32_t)maxTiles;
+    unsigned long long* halves = (unsigned long long*)state->ptr;
     for (uint32_t s = 0; s < kMaxPassSlots; ++s) {
         trhip_buffer_t* rec = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 4 * s);
         trhip_buffer_t* mask = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 4 * s + 1);
@@ -1007,32 +1189,49 @@ int recordPackShard(trhip::DispatchCtx& ctx)
         a.argsWords[s] = args->byteSize >= 16 ? 4u : 3u;
         a.recordCapacity[s] = cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;
     }
-    uint32_t grid = ctx.computeUnits() * 4u;
-    const uint32_t need = (3u * a.slotGroups + 255u) / 256u;
-    if (grid > need) grid = need;
-    if (grid == 0) grid = 1;
-    ctx.emit("main", [a, grid](hipStream_t s) {
-        hipLaunchKernelGGL(shardPackKernel, dim3(grid), dim3(256), 0, s, a);
+    // all workgroups resident at once (see the kernel): <= 4 per CU, 3 of them for the tiles
+    a.tileBlocks = (uint32_t)std::min<uint64_t>(maxTiles, (uint64_t)ctx.computeUnits() * 3u);
+    const uint32_t maskBlocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(((uint64_t)a.slotGroups + 4u * kPackThreads - 1u) / (4u * kPackThreads), 1u), ctx.computeUnits());
+    const uint32_t grid = a.tileBlocks + maskBlocks;
+    // which half this launch uses: one counter per state buffer, advanced at LAUNCH time (a recorded command is executed
+    // many times, and several recorded commands may share one state buffer)
+    static std::mutex mu;
+    static std::unordered_map<void*, std::shared_ptr<std::atomic<uint32_t>>> launches;
+    std::shared_ptr<std::atomic<uint32_t>> count;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        std::shared_ptr<std::atomic<uint32_t>>& c = launches[(void*)halves];
+        if (!c) c = std::make_shared<std::atomic<uint32_t>>(0u);
+        count = c;
+    }
+    ctx.emit("main", [a, grid, halves, count](hipStream_t s) {
+        ShardPackArgs l = a;
+        const uint32_t half = count->fetch_add(1u) & 1u;
+        l.status = halves + (size_t)half * a.maxTiles;
+        l.statusNext = halves + (size_t)(half ^ 1u) * a.maxTiles;
+        hipLaunchKernelGGL(shardPackKernel, dim3(grid), dim3(kPackThreads), 0, s, l);
         return trhip::launchStatus("shardPackKernel"); });
     return TRHIP_OK;
 }
 
 // "visibility_CS_UnpackShards": t0 = the gathered slots (world x slot words); pass slot s binds
 // u(4s) records, u(4s+1) masks, u(4s+2) visible list, u(4s+3) args (8 words: {G,1,1,G}, {V,1,1}, status);
-// push constants {world, slotGroups}.
+// push constants {world, slotGroups, slotRuns}.
 int recordUnpackShards(trhip::DispatchCtx& ctx)
 {
-    const uint32_t* push = (const uint32_t*)ctx.constants(0, 8);
+    const uint32_t* push = (const uint32_t*)ctx.constants(0, 12);
     trhip_buffer_t* recv = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 0);
-    TRHIP_REQUIRE(push && recv, "%s: needs push constants {world, slotGroups} and SRV t0 (gathered slots)", ctx.shaderName);
+    TRHIP_REQUIRE(push && recv, "%s: needs push constants {world, slotGroups, slotRuns} and SRV t0 (gathered slots)", ctx.shaderName);
     ShardUnpackArgs a;
     memset(&a, 0, sizeof a);
     a.world = push[0];
     a.slotGroups = push[1];
+    a.slotRuns = push[2];
     TRHIP_REQUIRE(a.world >= 1 && a.world <= kMaxRanks, "%s: world size %u outside [1, %u]", ctx.shaderName, a.world, kMaxRanks);
-    const uint64_t words = (uint64_t)a.world * (kSlotHeaderWords + 4ull * a.slotGroups);
-    TRHIP_REQUIRE(words < (1ull << 32), "%s: %u slots of %u groups exceed 2^32 words", ctx.shaderName, a.world, a.slotGroups);
+    const uint64_t words = (uint64_t)a.world * (kSlotHeaderWords + 4ull * a.slotRuns + a.slotGroups);
+    TRHIP_REQUIRE(words < (1ull << 32), "%s: %u slots of %u groups / %u runs exceed 2^32 words", ctx.shaderName, a.world, a.slotGroups, a.slotRuns);
     TRHIP_REQUIRE(recv->byteSize >= words * 4, "%s: gathered buffer smaller than world x slot", ctx.shaderName);
+    TRHIP_REQUIRE(((uintptr_t)recv->ptr & 15u) == 0, "%s: t0 not 16-byte aligned", ctx.shaderName);
     a.recv = (const uint32_t*)recv->ptr;
     MeshletCullArgs lists[kMaxPassSlots];
     uint64_t copyWords = 0;
@@ -1050,7 +1249,7 @@ int recordUnpackShards(trhip::DispatchCtx& ctx)
         a.masks[s] = (uint32_t*)mask->ptr;
         a.args[s] = (uint32_t*)args->ptr;
         a.capacity[s] = (uint32_t)cap;
-        copyWords += 4ull * std::min<uint64_t>(cap, (uint64_t)a.world * a.slotGroups);
+        copyWords += std::min<uint64_t>(cap, (uint64_t)a.world * a.slotGroups);
         MeshletCullArgs& l = lists[s];
         memset(&l, 0, sizeof l);
         l.dispatchArgs = a.args[s];
@@ -1069,9 +1268,9 @@ int recordUnpackShards(trhip::DispatchCtx& ctx)
     const uint64_t need = (copyWords + 255u) / 256u;
     if (grid > need) grid = (uint32_t)need;
     if (grid == 0) grid = 1;
-    ctx.emit("concat", [a, grid](hipStream_t s) {
-        hipLaunchKernelGGL(shardConcatKernel, dim3(grid), dim3(256), 0, s, a);
-        return trhip::launchStatus("shardConcatKernel"); });
+    ctx.emit("unpack", [a, grid](hipStream_t s) {
+        hipLaunchKernelGGL(shardUnpackKernel, dim3(grid), dim3(256), 0, s, a);
+        return trhip::launchStatus("shardUnpackKernel"); });
     for (uint32_t s = 0; s < kMaxPassSlots; ++s)
         if (a.records[s]) {
             const char prefix[] = { 's', 'l', 'o', 't', (char)('0' + s), '_', 0 };

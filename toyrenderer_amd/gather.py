@@ -3,17 +3,23 @@ contiguous ranges; every rank ends the frame with the WHOLE scene's amplificatio
 visible lists, bit-identical to a single-GPU frame (rank-major concatenation == single-GPU canonical
 order).  Not in the reference (single GPU, GraphicRHI.cpp:165).
 
-What crosses xGMI is the compact form of a rank's pass slots -- per group of 32 meshlets the 12-byte
-record and the 4-byte lane mask (1 bit per tested meshlet instead of 4 bytes per visible meshlet: 28 MB
-instead of 143 MB per frame on the 100 M-meshlet config) -- in one fixed-capacity SHARD SLOT per rank:
+What crosses xGMI is the compact form of a rank's pass slots, in one fixed-capacity SHARD SLOT per rank:
+  * per group of 32 meshlets the 4-byte lane mask (1 bit per tested meshlet instead of 4 bytes per visible meshlet);
+  * the amplification records as RUNS: the instance pass emits, per submitted instance, consecutive records
+    {instance, lod, 0}, {instance, lod, 32}, ... (gpuculling.hlsl:139-157), so a maximal run of records that continue
+    each other is 16 bytes {instance, lod, first group offset, index of its first record} whatever its length -- one
+    entry per submitted INSTANCE instead of 12 bytes per GROUP, lossless for any record array.
+On the 100 M-meshlet config (4 groups per instance) that is 8 bytes per group: 25 MB per frame instead of the 143 MB of
+the visible lists.
 
-    words [0, 16)             header: {G_s, V_s} of pass slot s at words 2s, 2s+1; word 8 = overflow flag
-    words [16, 16+3S)         records of pass slot 0, then 1, ... back to back (S = slot_groups)
-    words [16+3S, 16+4S)      lane masks in the same order
+    words [0, 16)             header: {G_s, V_s} of pass slot s at words 2s, 2s+1; word 8 = overflow flag (groups > S or
+                              runs > R); word 9 = groups dropped (Q2); words 10..13 = cumulative run count after pass slot s
+    words [16, 16+4R)         run entries of pass slot 0, then 1, ... back to back (R = slot_runs)
+    words [16+4R, 16+4R+S)    lane masks in the same order (S = slot_groups)
 
 Per frame:  pack (HIP kernel, compute stream)  ->  ONE equal-size all_gather_into_tensor (RCCL)  ->
-unpack (HIP kernels: rank-major concatenation with device-side offsets from the headers, then the same
-count/scan/expand list build the single-GPU path uses).  There is no host read-back, so nothing stalls
+unpack (HIP kernels: the whole-scene records rebuilt rank-major straight from the received run entries, the masks
+concatenated, device-side offsets from the headers; then the same count/scan/expand list build the single-GPU path uses).  There is no host read-back, so nothing stalls
 the submission of the next frame; the collective and the unpack run on a second stream and overlap the
 next frame's culling (send/receive buffers are double-buffered and guarded by events).
 
@@ -59,8 +65,15 @@ def shard_range(n: int, rank: int, world: int):
     return (rank * n) // world, ((rank + 1) * n) // world
 
 
-def slot_words(slot_groups: int) -> int:
-    return HEADER_WORDS + 4 * int(slot_groups)
+def slot_words(slot_groups: int, slot_runs: int | None = None) -> int:
+    """Words of one shard slot; slot_runs None = slot_groups (always enough: a run holds at least one group)."""
+    return HEADER_WORDS + 4 * int(slot_groups if slot_runs is None else slot_runs) + int(slot_groups)
+
+
+def shard_run_capacity(entries_in_shard: int) -> int:
+    """Upper bound of the runs one shard can emit in a frame over ALL its pass slots: a submitted id-list entry is one
+    run (its records continue each other), early and late sets are disjoint."""
+    return int(entries_in_shard)
 
 
 def shard_group_capacity(num_meshlets_per_lod: np.ndarray, mesh_of_entry: np.ndarray) -> int:
@@ -85,11 +98,12 @@ class ShardExchange:
     tests/exchange_ref.py); on the GPU the same sequence is driven natively (NativeShardExchange, ShardExchange.cpp)."""
 
     def __init__(self, dist, torch, world: int, rank: int, slot_groups: int, pass_slots=(0, 1),
-                 group_capacity: int | None = None, list_capacity: int | None = None, device="cpu"):
+                 group_capacity: int | None = None, list_capacity: int | None = None, device="cpu", slot_runs: int | None = None):
         assert 1 <= len(pass_slots) <= MAX_PASS_SLOTS and all(0 <= s < MAX_PASS_SLOTS for s in pass_slots)
         self.dist, self.torch, self.world, self.rank = dist, torch, int(world), int(rank)
         self.slot_groups = int(slot_groups)
-        self.slot_words = slot_words(slot_groups)
+        self.slot_runs = int(slot_groups if slot_runs is None else slot_runs)
+        self.slot_words = slot_words(slot_groups, self.slot_runs)
         assert self.world * self.slot_words < 2 ** 32, "gathered buffer exceeds 2^32 words"
         self.pass_slots = tuple(pass_slots)
         self.group_capacity = int(group_capacity if group_capacity is not None else self.world * self.slot_groups)
@@ -239,8 +253,10 @@ class NativeShardExchange:
 
     def __init__(self, renderer, dist, world: int, rank: int, slot_groups: int, pass_slots=(0, 1),
                  group_capacity: int | None = None, list_capacity: int | None = None, overlap: bool = True,
-                 stage_through_host: bool = False, loopback: bool = False, raster_depth: bool = False):
-        """raster_depth: the frames rasterise their own depth (trhost_set_raster_depth): adds the cross-rank MAX of the
+                 stage_through_host: bool = False, loopback: bool = False, raster_depth: bool = False,
+                 slot_runs: int | None = None):
+        """slot_runs: run entries a shard slot holds (shard_run_capacity of the largest shard; None = slot_groups).
+        raster_depth: the frames rasterise their own depth (trhost_set_raster_depth): adds the cross-rank MAX of the
         depth buffer before every HZB build (one more communicator / process group)."""
         import ctypes as C
 
@@ -256,6 +272,7 @@ class NativeShardExchange:
         d = host.ExchangeDesc()
         d.world, d.rank, d.slot_groups, d.group_capacity = self.world, self.rank, int(slot_groups), self.group_capacity
         d.list_capacity, d.overlap = self.list_capacity, int(bool(overlap))
+        d.slot_runs = int(slot_groups if slot_runs is None else slot_runs)
         d.pass_slot_mask = sum(1 << s for s in self.pass_slots)
         # which id lists exist on SOME rank: every rank posts the in-frame late-count collective of exactly those buckets
         n_op, n_am = C.c_uint32(), C.c_uint32()
