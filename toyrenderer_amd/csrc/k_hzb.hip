@@ -229,25 +229,44 @@ struct QuadArgs
     uint32_t width, height, mips, total;
     uint32_t mipOffset[16];       // texels
     uint32_t quadOffset[16];      // entries
+    uint32_t blocksPerRow[16];    // (mip width >> 3) + 1
+    uint64_t rowMagic[16];        // ceil(2^40 / blocksPerRow): block / blocksPerRow == (block * magic) >> 40 (blocks < 2^25, rows < 2^15)
 };
 
+// Four entries per thread, their sixteen texel loads in flight together (the kernel is a chain of one dependent load per
+// entry otherwise: 33 us for 11 MB next to the instance pass it shares the chip with); the block row comes from a
+// multiplication instead of a 32-bit division (~40 VALU instructions per entry).
 __global__ __launch_bounds__(256) void hzbQuadBuildKernel(QuadArgs a)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= a.total) return;
-    uint32_t k = 0;
-    for (uint32_t m = 1; m < a.mips; ++m) k += i >= a.quadOffset[m] ? 1u : 0u;
-    const uint32_t mw = (a.width >> k) ? (a.width >> k) : 1u, mh = (a.height >> k) ? (a.height >> k) : 1u;
-    const uint32_t j = i - a.quadOffset[k];
-    const uint32_t bpr = (mw >> 3) + 1u, blk = j >> 6;
-    uint32_t X = (blk % bpr) * 8u + (j & 7u), Y = (blk / bpr) * 8u + ((j >> 3) & 7u);
-    X = X < mw ? X : mw; Y = Y < mh ? Y : mh;                      // padding entries repeat the edge
-    const uint32_t xa = X ? X - 1u : 0u, xb = X < mw ? X : mw - 1u;
-    const uint32_t ya = Y ? Y - 1u : 0u, yb = Y < mh ? Y : mh - 1u;
-    const _Float16* t = a.base + a.mipOffset[k];
-    const float d00 = (float)t[ya * mw + xa], d01 = (float)t[ya * mw + xb];
-    const float d10 = (float)t[yb * mw + xa], d11 = (float)t[yb * mw + xb];
-    a.out[i] = (_Float16)cm::min_(cm::min_(cm::min_(d00, d01), d10), d11);     // min of fp16 values: exact
+    constexpr uint32_t kPer = 4;
+    const uint32_t stride = gridDim.x * 256u;
+    const _Float16* __restrict__ src = a.base;
+    _Float16* __restrict__ dst = a.out;
+    for (uint32_t first = blockIdx.x * 256u + threadIdx.x; first < a.total; first += kPer * stride) {
+        float d[kPer][4];
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t i = first + u * stride < a.total ? first + u * stride : a.total - 1u;      // clamped: loaded, not stored
+            uint32_t k = 0;
+            for (uint32_t m = 1; m < a.mips; ++m) k += i >= a.quadOffset[m] ? 1u : 0u;
+            const uint32_t mw = (a.width >> k) ? (a.width >> k) : 1u, mh = (a.height >> k) ? (a.height >> k) : 1u;
+            const uint32_t j = i - a.quadOffset[k];
+            const uint32_t blk = j >> 6;
+            const uint32_t brow = (uint32_t)(((uint64_t)blk * a.rowMagic[k]) >> 40), bcol = blk - brow * a.blocksPerRow[k];
+            uint32_t X = bcol * 8u + (j & 7u), Y = brow * 8u + ((j >> 3) & 7u);
+            X = X < mw ? X : mw; Y = Y < mh ? Y : mh;                      // padding entries repeat the edge
+            const uint32_t xa = X ? X - 1u : 0u, xb = X < mw ? X : mw - 1u;
+            const uint32_t ya = Y ? Y - 1u : 0u, yb = Y < mh ? Y : mh - 1u;
+            const _Float16* t = src + a.mipOffset[k];
+            d[u][0] = (float)t[ya * mw + xa]; d[u][1] = (float)t[ya * mw + xb];
+            d[u][2] = (float)t[yb * mw + xa]; d[u][3] = (float)t[yb * mw + xb];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t i = first + u * stride;
+            if (i < a.total) dst[i] = (_Float16)cm::min_(cm::min_(cm::min_(d[u][0], d[u][1]), d[u][2]), d[u][3]);     // min of fp16 values: exact
+        }
+    }
 }
 
 QuadArgs quadArgs(const trhip_texture_t* tex)
@@ -257,7 +276,12 @@ QuadArgs quadArgs(const trhip_texture_t* tex)
     a.base = (const _Float16*)tex->ptr;
     a.out = (_Float16*)tex->quad;
     a.width = tex->width; a.height = tex->height; a.mips = tex->mips; a.total = tex->quadTotal;
-    for (uint32_t i = 0; i < tex->mips; ++i) { a.mipOffset[i] = (uint32_t)(tex->mipOffset[i] / 2); a.quadOffset[i] = tex->quadOffset[i]; }
+    for (uint32_t i = 0; i < tex->mips; ++i) {
+        a.mipOffset[i] = (uint32_t)(tex->mipOffset[i] / 2);
+        a.quadOffset[i] = tex->quadOffset[i];
+        a.blocksPerRow[i] = (tex->mipW(i) >> 3) + 1u;
+        a.rowMagic[i] = ((1ull << 40) + a.blocksPerRow[i] - 1u) / a.blocksPerRow[i];
+    }
     return a;
 }
 
@@ -395,7 +419,7 @@ int hzbQuadLaunchBuild(trhip_texture_t* tex, hipStream_t s)
     const uint64_t v = tex->version;                   // called while commands are submitted: every earlier write is counted
     if (tex->quadBuiltVersion == v) return TRHIP_OK;   // nothing wrote the HZB since the last build
     const QuadArgs a = quadArgs(tex);
-    hipLaunchKernelGGL(hzbQuadBuildKernel, dim3((a.total + 255u) / 256u), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(hzbQuadBuildKernel, dim3((a.total + 1023u) / 1024u), dim3(256), 0, s, a);
     tex->quadBuiltVersion = v;
     return launchStatus("hzbQuadBuildKernel");
 }
