@@ -117,7 +117,10 @@ __global__ __launch_bounds__(256) void instanceCacheKernel(const BasePassInstanc
     }
 }
 
-constexpr uint32_t kTilesPerAxis = 32;
+#ifndef TR_TILES_PER_AXIS
+#define TR_TILES_PER_AXIS 32
+#endif
+constexpr uint32_t kTilesPerAxis = TR_TILES_PER_AXIS;
 constexpr uint32_t kNumTiles = kTilesPerAxis * kTilesPerAxis;
 constexpr uint32_t kPermHeaderWords = 64;
 #ifndef TR_MIN_BINNED
@@ -308,14 +311,47 @@ template <int LATE>
 __global__ __launch_bounds__(kScanThreads) void instanceScanKernel(InstanceCullArgs a)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t n = threadCount<LATE>(a);
-    const uint32_t activeBlocks = activeBigBlocks<LATE>(a, n);
     if (blockIdx.x != 0) {
         // ---- tile columns: H[b][t] <- groups of tile t in workgroups < b; T[t] <- all of them -------------------------
-        if (n < kMinBinnedEntries) return;
+        // The kernel is a chain of dependent round trips (list length -> rows -> sums -> rows again) around very little
+        // work: 11 us for the early AND for the 8x shorter late list.  So the rows are striped by the CAPACITY of the pass
+        // (known at launch) and loaded before the list length is: one round trip for everything, rows beyond the active
+        // workgroups are masked afterwards (they hold an earlier frame's histogram), values stay in registers for the
+        // second walk.
         __shared__ uint32_t s_stripe[kScanStripes][kScanTilesPerGroup];
         const uint32_t tl = tid % kScanTilesPerGroup, stripe = tid / kScanTilesPerGroup;
         const uint32_t tile = (blockIdx.x - 1u) * kScanTilesPerGroup + tl;
+        constexpr uint32_t kMaxPer = 32;
+        const uint32_t perCap = (a.numBlocks + kScanStripes - 1) / kScanStripes;
+        // (early pass only: the late list is ~8x shorter than its capacity, and reading the capacity's rows next to the
+        // list build on the side stream made the late scan slower, 20 -> 26 us between events)
+        if (!LATE && perCap <= kMaxPer) {
+            uint32_t v[kMaxPer];
+            const uint32_t r0 = stripe * perCap;
+#pragma unroll
+            for (uint32_t r = 0; r < kMaxPer; ++r)
+                v[r] = (r < perCap && r0 + r < a.numBlocks) ? a.tileHist[(uint64_t)(r0 + r) * kNumTiles + tile] : 0u;
+            const uint32_t n = threadCount<LATE>(a);
+            if (n < kMinBinnedEntries) return;
+            const uint32_t activeBlocks = activeBigBlocks<LATE>(a, n);
+            uint32_t sum = 0;
+#pragma unroll
+            for (uint32_t r = 0; r < kMaxPer; ++r) { v[r] = r0 + r < activeBlocks ? v[r] : 0u; sum += v[r]; }
+            s_stripe[stripe][tl] = sum;
+            __syncthreads();
+            uint32_t run = 0;
+            for (uint32_t sIdx = 0; sIdx < stripe; ++sIdx) run += s_stripe[sIdx][tl];
+#pragma unroll
+            for (uint32_t r = 0; r < kMaxPer; ++r) {
+                if (r < perCap && r0 + r < activeBlocks) a.tileHist[(uint64_t)(r0 + r) * kNumTiles + tile] = run;
+                run += v[r];
+            }
+            if (stripe == kScanStripes - 1u) a.tileTotal[tile] = run;
+            return;
+        }
+        const uint32_t n = threadCount<LATE>(a);
+        if (n < kMinBinnedEntries) return;
+        const uint32_t activeBlocks = activeBigBlocks<LATE>(a, n);
         const uint32_t per = (activeBlocks + kScanStripes - 1) / kScanStripes;
         const uint32_t b0 = stripe * per < activeBlocks ? stripe * per : activeBlocks;
         const uint32_t b1 = b0 + per < activeBlocks ? b0 + per : activeBlocks;
@@ -333,6 +369,14 @@ __global__ __launch_bounds__(kScanThreads) void instanceScanKernel(InstanceCullA
         if (stripe == kScanStripes - 1u) a.tileTotal[tile] = run;
         return;
     }
+    // workgroup 0: the loads its last step needs and the first slice of the workgroup sums are requested together with the
+    // list length (all within the capacity of the pass), not after it
+    const uint32_t argsX0 = a.dispatchArgs[0];
+    const uint32_t late0 = LATE ? 0u : *a.lateCount;
+    const uint32_t firstG = !LATE && tid < a.numBlocks ? a.blockGroups[tid] : 0u;
+    const uint64_t firstLS = !LATE && tid < a.numBlocks ? a.blockLateSubmit[tid] : 0ull;
+    const uint32_t n = threadCount<LATE>(a);
+    const uint32_t activeBlocks = activeBigBlocks<LATE>(a, n);
     // ---- workgroup 0: exclusive scan over the per-workgroup sums; final counters ------------------------------------
     __shared__ uint32_t s_wg[2][(kScanThreads / 64)];
     __shared__ uint64_t s_wls[2][(kScanThreads / 64)];
@@ -342,8 +386,8 @@ __global__ __launch_bounds__(kScanThreads) void instanceScanKernel(InstanceCullA
     uint64_t carryLS = 0;
     for (uint32_t base = 0; base < activeBlocks; base += kScanThreads) {
         const uint32_t i = base + tid;
-        const uint32_t g = i < activeBlocks ? a.blockGroups[i] : 0u;
-        const uint64_t ls = i < activeBlocks ? a.blockLateSubmit[i] : 0ull;
+        const uint32_t g = i < activeBlocks ? (!LATE && base == 0 ? firstG : a.blockGroups[i]) : 0u;
+        const uint64_t ls = i < activeBlocks ? (!LATE && base == 0 ? firstLS : a.blockLateSubmit[i]) : 0ull;
         const uint32_t incG = waveInclusiveScan(g, lane);
         // 64-bit inclusive scan of (late | submits << 32): two 32-bit halves, no carry between them (each < 2^32)
         const uint32_t incLo = waveInclusiveScan((uint32_t)ls, lane), incHi = waveInclusiveScan((uint32_t)(ls >> 32), lane);
@@ -369,8 +413,8 @@ __global__ __launch_bounds__(kScanThreads) void instanceScanKernel(InstanceCullA
     if (tid == 0) { s_carryG = carryG; s_carryLS = carryLS; }
     __syncthreads();
     if (tid == 0) {
-        const uint32_t baseX = a.dispatchArgs[0];
-        const uint32_t baseLate = LATE ? 0u : *a.lateCount;
+        const uint32_t baseX = argsX0;
+        const uint32_t baseLate = late0;
         a.bases[0] = baseX;
         a.bases[1] = baseLate;
         const uint32_t X = baseX + s_carryG;                  // gpuculling.hlsl:65 (counter still counts drops, Q2)

@@ -287,7 +287,9 @@ static int deviceCreate(int index, void* stream, bool external, trhip_device* ou
         // +0.06..0.16 ms per frame).  A different priority class is a different queue.
         int lowest = 0, highest = 0;
         TRHIP_HIP(hipDeviceGetStreamPriorityRange(&lowest, &highest));
-        TRHIP_HIP(hipStreamCreateWithPriority(&dev->sideStream, hipStreamNonBlocking, highest));
+        int sidePriority = highest;
+        if (const char* e = getenv("TRHIP_SIDE_PRIORITY")) sidePriority = atoi(e) < 0 ? highest : atoi(e) > 0 ? lowest : 0;   // experiments
+        TRHIP_HIP(hipStreamCreateWithPriority(&dev->sideStream, hipStreamNonBlocking, sidePriority));
         TRHIP_HIP(hipEventCreateWithFlags(&dev->evFork, hipEventDisableTiming));
         for (hipEvent_t& e : dev->runDone) TRHIP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
