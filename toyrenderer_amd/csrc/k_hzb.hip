@@ -230,42 +230,59 @@ struct QuadArgs
     uint32_t mipOffset[16];       // texels
     uint32_t quadOffset[16];      // entries
     uint32_t blocksPerRow[16];    // (mip width >> 3) + 1
-    uint64_t rowMagic[16];        // ceil(2^40 / blocksPerRow): block / blocksPerRow == (block * magic) >> 40 (blocks < 2^25, rows < 2^15)
+    uint32_t stripsPerRow[16];    // ceil(blocksPerRow / kQuadStripBlocks)
+    uint32_t firstStrip[17];      // strips (= workgroups) of the mips before k
 };
 
-// Four entries per thread, their sixteen texel loads in flight together (the kernel is a chain of one dependent load per
-// entry otherwise: 33 us for 11 MB next to the instance pass it shares the chip with); the block row comes from a
-// multiplication instead of a 32-bit division (~40 VALU instructions per entry).
+// A workgroup builds one STRIP of the table: kQuadStripBlocks consecutive 8 x 8 blocks of one block row = 256 x 8
+// entries, contiguous in the table.  Their footprints are 257 x 9 texels: loaded once (rows of consecutive texels, clamped
+// to the edge, which is exactly what the padding entries and the border entries need) into LDS, then every thread takes
+// eight entries = four LDS reads each.  (One thread per entry with four 2-byte global loads took 33 us next to the
+// instance pass for 11 MB of traffic, four entries per thread 30 us: a chain of dependent little loads.  Row stride 257
+// words: the 8 x 8 lanes of a wave spread over 15 banks.)
+constexpr uint32_t kQuadStripBlocks = 32;
+constexpr uint32_t kQuadStripCols = kQuadStripBlocks * 8;          // 256 entries per entry row
+
 __global__ __launch_bounds__(256) void hzbQuadBuildKernel(QuadArgs a)
 {
-    constexpr uint32_t kPer = 4;
-    const uint32_t stride = gridDim.x * 256u;
-    const _Float16* __restrict__ src = a.base;
-    _Float16* __restrict__ dst = a.out;
-    for (uint32_t first = blockIdx.x * 256u + threadIdx.x; first < a.total; first += kPer * stride) {
-        float d[kPer][4];
+    __shared__ float s_t[9][kQuadStripCols + 1];
+    const uint32_t tid = threadIdx.x;
+    uint32_t k = 0;
+    for (uint32_t m = 1; m < a.mips; ++m) k += blockIdx.x >= a.firstStrip[m] ? 1u : 0u;
+    const uint32_t mw = (a.width >> k) ? (a.width >> k) : 1u, mh = (a.height >> k) ? (a.height >> k) : 1u;
+    const uint32_t strip = blockIdx.x - a.firstStrip[k];
+    const uint32_t brow = strip / a.stripsPerRow[k], seg = strip - brow * a.stripsPerRow[k];
+    const uint32_t X0 = seg * kQuadStripCols, Y0 = brow * 8u;
+    const _Float16* __restrict__ t = a.base + a.mipOffset[k];
+    // texel (Y0 - 1 + r, X0 - 1 + c), clamped
+    {
+        const int tx = min(max((int)(X0 + tid) - 1, 0), (int)mw - 1);
+        float v[9];
 #pragma unroll
-        for (uint32_t u = 0; u < kPer; ++u) {
-            const uint32_t i = first + u * stride < a.total ? first + u * stride : a.total - 1u;      // clamped: loaded, not stored
-            uint32_t k = 0;
-            for (uint32_t m = 1; m < a.mips; ++m) k += i >= a.quadOffset[m] ? 1u : 0u;
-            const uint32_t mw = (a.width >> k) ? (a.width >> k) : 1u, mh = (a.height >> k) ? (a.height >> k) : 1u;
-            const uint32_t j = i - a.quadOffset[k];
-            const uint32_t blk = j >> 6;
-            const uint32_t brow = (uint32_t)(((uint64_t)blk * a.rowMagic[k]) >> 40), bcol = blk - brow * a.blocksPerRow[k];
-            uint32_t X = bcol * 8u + (j & 7u), Y = brow * 8u + ((j >> 3) & 7u);
-            X = X < mw ? X : mw; Y = Y < mh ? Y : mh;                      // padding entries repeat the edge
-            const uint32_t xa = X ? X - 1u : 0u, xb = X < mw ? X : mw - 1u;
-            const uint32_t ya = Y ? Y - 1u : 0u, yb = Y < mh ? Y : mh - 1u;
-            const _Float16* t = src + a.mipOffset[k];
-            d[u][0] = (float)t[ya * mw + xa]; d[u][1] = (float)t[ya * mw + xb];
-            d[u][2] = (float)t[yb * mw + xa]; d[u][3] = (float)t[yb * mw + xb];
+        for (uint32_t r = 0; r < 9; ++r) {
+            const int ty = min(max((int)(Y0 + r) - 1, 0), (int)mh - 1);
+            v[r] = (float)t[(uint32_t)ty * mw + (uint32_t)tx];
+        }
+        float edge = 0.f;
+        if (tid < 9) {
+            const int ty = min(max((int)(Y0 + tid) - 1, 0), (int)mh - 1);
+            const int ex = min((int)(X0 + kQuadStripCols) - 1, (int)mw - 1);
+            edge = (float)t[(uint32_t)ty * mw + (uint32_t)ex];
         }
 #pragma unroll
-        for (uint32_t u = 0; u < kPer; ++u) {
-            const uint32_t i = first + u * stride;
-            if (i < a.total) dst[i] = (_Float16)cm::min_(cm::min_(cm::min_(d[u][0], d[u][1]), d[u][2]), d[u][3]);     // min of fp16 values: exact
-        }
+        for (uint32_t r = 0; r < 9; ++r) s_t[r][tid] = v[r];
+        if (tid < 9) s_t[tid][kQuadStripCols] = edge;
+    }
+    __syncthreads();
+    const uint32_t blocksHere = min(kQuadStripBlocks, a.blocksPerRow[k] - seg * kQuadStripBlocks);
+    _Float16* __restrict__ dst = a.out + a.quadOffset[k] + ((uint64_t)brow * a.blocksPerRow[k] + (uint64_t)seg * kQuadStripBlocks) * 64u;
+#pragma unroll
+    for (uint32_t e = 0; e < 8; ++e) {
+        const uint32_t i = e * 256u + tid;                       // entry of the strip: block i >> 6, row (i >> 3) & 7, column i & 7
+        const uint32_t blk = i >> 6;
+        if (blk >= blocksHere) continue;
+        const uint32_t xl = blk * 8u + (i & 7u), yl = (i >> 3) & 7u;
+        dst[i] = (_Float16)cm::min_(cm::min_(cm::min_(s_t[yl][xl], s_t[yl][xl + 1]), s_t[yl + 1][xl]), s_t[yl + 1][xl + 1]);     // min of fp16 values: exact
     }
 }
 
@@ -276,12 +293,16 @@ QuadArgs quadArgs(const trhip_texture_t* tex)
     a.base = (const _Float16*)tex->ptr;
     a.out = (_Float16*)tex->quad;
     a.width = tex->width; a.height = tex->height; a.mips = tex->mips; a.total = tex->quadTotal;
+    uint32_t strips = 0;
     for (uint32_t i = 0; i < tex->mips; ++i) {
         a.mipOffset[i] = (uint32_t)(tex->mipOffset[i] / 2);
         a.quadOffset[i] = tex->quadOffset[i];
         a.blocksPerRow[i] = (tex->mipW(i) >> 3) + 1u;
-        a.rowMagic[i] = ((1ull << 40) + a.blocksPerRow[i] - 1u) / a.blocksPerRow[i];
+        a.stripsPerRow[i] = (a.blocksPerRow[i] + kQuadStripBlocks - 1u) / kQuadStripBlocks;
+        a.firstStrip[i] = strips;
+        strips += a.stripsPerRow[i] * ((tex->mipH(i) >> 3) + 1u);
     }
+    a.firstStrip[tex->mips] = strips;
     return a;
 }
 
@@ -419,7 +440,7 @@ int hzbQuadLaunchBuild(trhip_texture_t* tex, hipStream_t s)
     const uint64_t v = tex->version;                   // called while commands are submitted: every earlier write is counted
     if (tex->quadBuiltVersion == v) return TRHIP_OK;   // nothing wrote the HZB since the last build
     const QuadArgs a = quadArgs(tex);
-    hipLaunchKernelGGL(hzbQuadBuildKernel, dim3((a.total + 1023u) / 1024u), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(hzbQuadBuildKernel, dim3(a.firstStrip[a.mips]), dim3(256), 0, s, a);
     tex->quadBuiltVersion = v;
     return launchStatus("hzbQuadBuildKernel");
 }
