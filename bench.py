@@ -381,14 +381,28 @@ def main():
         dist.destroy_process_group()
 
 
+def free_rendezvous_port() -> int:
+    """A free TCP port on 127.0.0.1 BELOW the ephemeral range (32768+): a port the kernel hands out for bind(0) can be
+    taken by some process's outgoing connection before torch.distributed.run binds it (seen once: EADDRINUSE)."""
+    import random
+    import socket
+    rng = random.Random(os.getpid() ^ int.from_bytes(os.urandom(4), "little"))
+    for _ in range(200):
+        port = rng.randrange(20000, 32000)
+        with socket.socket() as s:
+            try:
+                s.bind(("127.0.0.1", port))
+            except OSError:
+                continue
+            return port
+    raise RuntimeError("no free port in [20000, 32000)")
+
+
 def self_launch(n: int) -> int:
     """Start `n` ranks of this script through torch.distributed.run as a child process (rendezvous on 127.0.0.1, a free
     port), let its stdout (rank 0's one JSON line) and stderr pass straight through, return its exit code."""
-    import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_rendezvous_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)

@@ -238,13 +238,12 @@ def test_ranks_sharing_one_gpu_equal_one_rank(world):
 
 def _run_ranks(world, mode, tmp_path, extra_env=None):
     import os
-    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    sys.path.insert(0, root)
+    from bench import free_rendezvous_port
+    port = free_rendezvous_port()
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(extra_env or {})
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",

@@ -82,7 +82,8 @@ def _worker(rank, world, port, out_dir):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_cull_plus_gather_equals_single_process(tmp_path, world):
-    port = 29500 + (os.getpid() % 2000) + world
+    from bench import free_rendezvous_port
+    port = free_rendezvous_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert (tmp_path / f"ok_{world}").exists()
 

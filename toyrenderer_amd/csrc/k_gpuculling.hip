@@ -483,9 +483,22 @@ __global__ __launch_bounds__(kBigThreads) void instanceEmitKernel(InstanceCullAr
             continue;
         }
         const uint32_t id = a.ids[t];
-        for (uint32_t i = 0; i < groups; ++i) {                                         // :76-84
-            MeshletAmplificationData rec = { id, lod, i * kNumThreadsPerWave };
-            a.records[off + i] = rec;
+        {                                                                               // :76-84
+            // four 12-byte records = three 16-byte stores (dword-aligned: the back end runs in unaligned-access mode): a
+            // quarter of the store instructions, each of which touches a line per lane or two
+            struct __attribute__((packed, aligned(4))) Quad { uint32_t x, y, z, w; };
+            uint32_t* dst = reinterpret_cast<uint32_t*>(a.records + off);
+            uint32_t i = 0;
+            for (; i + 4u <= groups; i += 4u) {
+                const uint32_t o = i * kNumThreadsPerWave;
+                *reinterpret_cast<Quad*>(dst + 3u * i) = Quad{ id, lod, o, id };
+                *reinterpret_cast<Quad*>(dst + 3u * i + 4u) = Quad{ lod, o + kNumThreadsPerWave, id, lod };
+                *reinterpret_cast<Quad*>(dst + 3u * i + 8u) = Quad{ o + 2u * kNumThreadsPerWave, id, lod, o + 3u * kNumThreadsPerWave };
+            }
+            for (; i < groups; ++i) {
+                MeshletAmplificationData rec = { id, lod, i * kNumThreadsPerWave };
+                a.records[off + i] = rec;
+            }
         }
         if (groups != 0 && binned) {                                                    // place in the tile-ordered list
             const uint32_t p = atomicAdd(&s_cursor[a.tileOf[t]], groups);
