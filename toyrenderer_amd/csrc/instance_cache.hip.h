@@ -16,8 +16,14 @@ struct InstanceCullCache
                                     // floats, then {maxScale, 0, 0, 0}: everything the meshlet cull reads per record
     const float* maxScale;          // toyrenderer_common.hlsli:134-140
     const uint32_t* numLODs;
-    const uint2* lodInfo;           // [id][kMaxNumMeshLODs]  {m_NumMeshlets, m_MeshletDataBufferIdx}
-    const float* error;             // [id][kMaxNumMeshLODs]
+    const uint2* lodInfo;           // [lod][id]  {m_NumMeshlets, m_MeshletDataBufferIdx}: one plane per LOD, so that the 8 bytes
+                                    // of the selected LOD are a coalesced read over consecutive ids (as [id][lod] a lane pulled
+                                    // a 64-byte granule for them: 2/3 of the bytes classify moved on C3)
+    const float* error;             // [lod][id]
+    uint64_t stride;                // ids per plane
+
+    __host__ __device__ const uint2& lod(uint32_t id, uint32_t l) const { return lodInfo[(uint64_t)l * stride + id]; }
+    __host__ __device__ const float& err(uint32_t id, uint32_t l) const { return error[(uint64_t)l * stride + id]; }
 };
 
 constexpr uint64_t kInstanceCacheBytesPerInstance = 64 + 16 + 4 + 4 + 3 * 4 * interop::kMaxNumMeshLODs;
@@ -32,5 +38,6 @@ inline InstanceCullCache instanceCacheLayout(void* base, uint64_t n)
     c.numLODs = (const uint32_t*)p;         p += 4 * n;
     c.lodInfo = (const uint2*)p;            p += 8ull * interop::kMaxNumMeshLODs * n;
     c.error = (const float*)p;
+    c.stride = n;
     return c;
 }

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(kCullBlock) void meshletCullKernel(MeshletCullArgs 
                 uint32_t cnt = cur.w;
                 if (!usePerm) {
                     const uint32_t lodIdx = cur.z < kMaxNumMeshLODs ? cur.z : kMaxNumMeshLODs - 1u;
-                    const uint2 li = a.cache.lodInfo[(uint64_t)cid * kMaxNumMeshLODs + lodIdx];
+                    const uint2 li = a.cache.lod(cid, lodIdx);
                     const uint32_t off = cur.w;
                     cnt = li.x > off ? li.x - off : 0u;
                     base = (uint64_t)li.y + off;

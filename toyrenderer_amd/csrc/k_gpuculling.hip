@@ -112,8 +112,8 @@ __global__ __launch_bounds__(256) void instanceCacheKernel(const BasePassInstanc
     const_cast<uint32_t*>(c.numLODs)[i] = numLODs;
 #pragma unroll
     for (uint32_t l = 0; l < kMaxNumMeshLODs; ++l) {
-        const_cast<uint2*>(c.lodInfo)[(uint64_t)i * kMaxNumMeshLODs + l] = make_uint2(nm[l], mb[l]);
-        const_cast<float*>(c.error)[(uint64_t)i * kMaxNumMeshLODs + l] = err[l];
+        const_cast<uint2&>(c.lod(i, l)) = make_uint2(nm[l], mb[l]);
+        const_cast<float&>(c.err(i, l)) = err[l];
     }
 }
 
@@ -197,8 +197,6 @@ __device__ __forceinline__ uint32_t classify(const InstanceCullArgs& a, uint32_t
 
     // SubmitInstance :35-62
     const uint32_t numLODs = a.cache.numLODs[cid];
-    const uint2* lodInfo = a.cache.lodInfo + (uint64_t)cid * kMaxNumMeshLODs;
-    const float* lodError = a.cache.error + (uint64_t)cid * kMaxNumMeshLODs;
     uint32_t lod = 0;
     if (k.m_ForcedMeshLOD != kInvalidMeshLOD) {
         const uint32_t last = numLODs - 1u;
@@ -208,10 +206,10 @@ __device__ __forceinline__ uint32_t classify(const InstanceCullArgs& a, uint32_t
         const float threshold = distance * k.m_MeshLODTarget / ms;
         const uint32_t n = numLODs < kMaxNumMeshLODs ? numLODs : kMaxNumMeshLODs;
         for (uint32_t i = 1; i < n; ++i)
-            if (lodError[i] < threshold) lod = i;
+            if (a.cache.err(cid, i) < threshold) lod = i;
     }
     lod = lod < kMaxNumMeshLODs ? lod : kMaxNumMeshLODs - 1u;                       // never index past the table
-    const uint2 li = lodInfo[lod];                                                  // {m_NumMeshlets, m_MeshletDataBufferIdx}
+    const uint2 li = a.cache.lod(cid, lod);                                         // {m_NumMeshlets, m_MeshletDataBufferIdx}
     *lodOut = li;
     const uint32_t numMeshlets = li.x;
     const uint32_t groups = (numMeshlets + kNumThreadsPerWave - 1u) / kNumThreadsPerWave; // DivideAndRoundUp
