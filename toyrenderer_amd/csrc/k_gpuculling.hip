@@ -466,22 +466,17 @@ __global__ __launch_bounds__(kBigThreads) void instanceEmitKernel(InstanceCullAr
     const uint32_t baseL = a.bases[1] + (uint32_t)a.blockLateSubmit[blockIdx.x];
     for (uint32_t e = 0; e < kBigPerThread; ++e) {
         const uint32_t t = blockIdx.x * kBigChunk + e * kBigThreads + tid;
-        if (t >= n) continue;
-        const uint32_t word = a.word[t];
-        if (word & kWordLate) {                                                         // :162-167
-            a.lateIds[baseL + a.localOff[t]] = a.ids[t];
-            continue;
-        }
-        if (!(word & kWordSubmit)) continue;
+        const uint32_t word = t < n ? a.word[t] : 0u;
+        if (word & kWordLate) a.lateIds[baseL + a.localOff[t]] = a.ids[t];              // :162-167
+        const bool submit = (word & kWordSubmit) != 0 && !(word & kWordLate);
         const uint32_t groups = word & kGroupMask;
         const uint32_t lod = (word >> 27) & 7u;
-        const uint32_t off = baseG + a.localOff[t];                                     // :65
-        if (off + groups >= a.maxGroups) {                                              // :69-74 (Q2)
-            if (groups != 0 && off < a.maxGroups && a.argsWords > 3) a.dispatchArgs[3] = off;
-            continue;
-        }
-        const uint32_t id = a.ids[t];
-        {                                                                               // :76-84
+        const uint32_t off = submit ? baseG + a.localOff[t] : 0u;                       // :65
+        const bool dropped = submit && off + groups >= a.maxGroups;                     // :69-74 (Q2)
+        if (dropped && groups != 0 && off < a.maxGroups && a.argsWords > 3) a.dispatchArgs[3] = off;
+        const bool emitRec = submit && !dropped;
+        const uint32_t id = emitRec ? a.ids[t] : 0u;
+        if (emitRec) {                                                                  // :76-84
             // four 12-byte records = three 16-byte stores (dword-aligned: the back end runs in unaligned-access mode): a
             // quarter of the store instructions, each of which touches a line per lane or two
             struct __attribute__((packed, aligned(4))) Quad { uint32_t x, y, z, w; };
@@ -498,18 +493,37 @@ __global__ __launch_bounds__(kBigThreads) void instanceEmitKernel(InstanceCullAr
                 a.records[off + i] = rec;
             }
         }
-        if (groups != 0 && binned) {                                                    // place in the tile-ordered list
-            const uint32_t p = atomicAdd(&s_cursor[a.tileOf[t]], groups);
-            // the record resolved through the LOD table by classify, once per instance (basepass.hlsl:54-63): the meshlet
-            // cull then reads 16 bytes of this list and one 64-byte block of the instance cache per record, nothing else
+        // Place in the tile-ordered list: the record resolved through the LOD table by classify, once per instance
+        // (basepass.hlsl:54-63): the meshlet cull then reads 16 bytes of this list and one 64-byte block of the instance
+        // cache per record, nothing else.  A run's entries are contiguous, the runs of a wave's lanes are not: written lane
+        // by lane, each of the (typically four) 16-byte stores touches 64 lines.  So FOUR LANES write one run's first four
+        // entries (64 contiguous bytes): 16 lines per store instruction.  Longer runs finish lane by lane.
+        const bool place = emitRec && groups != 0 && binned;
+        uint32_t p = 0, numMeshlets = 0, mbase = 0;
+        if (place) {
+            p = atomicAdd(&s_cursor[a.tileOf[t]], groups);
             const uint2 li = a.lodSel[t];
-            const uint32_t numMeshlets = li.x, base = li.y;
-            for (uint32_t i = 0; i < groups; ++i) {
-                const uint32_t first = i * kNumThreadsPerWave;
-                const uint32_t cnt = numMeshlets > first ? (numMeshlets - first < kNumThreadsPerWave ? numMeshlets - first : kNumThreadsPerWave) : 0u;
-                if (p + i < a.permCapacity) a.perm[p + i] = make_uint4(off + i, id, base + first, cnt);
+            numMeshlets = li.x; mbase = li.y;
+        }
+        const uint32_t head = place ? (groups < 4u ? groups : 4u) : 0u;
+        const uint32_t j = lane & 3u;
+#pragma unroll
+        for (uint32_t it = 0; it < 4; ++it) {
+            const int src = (int)(it * 16u + (lane >> 2));
+            const uint32_t sp = __shfl(p, src), soff = __shfl(off, src), sid = __shfl(id, src);
+            const uint32_t sbase = __shfl(mbase, src), snm = __shfl(numMeshlets, src), shead = __shfl(head, src);
+            if (j < shead) {
+                const uint32_t first = j * kNumThreadsPerWave;
+                const uint32_t cnt = snm > first ? (snm - first < kNumThreadsPerWave ? snm - first : kNumThreadsPerWave) : 0u;
+                if (sp + j < a.permCapacity) a.perm[sp + j] = make_uint4(soff + j, sid, sbase + first, cnt);
             }
         }
+        if (place)
+            for (uint32_t i = 4; i < groups; ++i) {
+                const uint32_t first = i * kNumThreadsPerWave;
+                const uint32_t cnt = numMeshlets > first ? (numMeshlets - first < kNumThreadsPerWave ? numMeshlets - first : kNumThreadsPerWave) : 0u;
+                if (p + i < a.permCapacity) a.perm[p + i] = make_uint4(off + i, id, mbase + first, cnt);
+            }
     }
 }
 
