@@ -57,8 +57,8 @@ struct InstanceCullArgs
     // screen-tile binning of the submitted instances (PROCESSING order of the meshlet pass only; the
     // record order above is untouched): a counting sort by tile, see "Large passes" below; perm lives in the records
     // buffer's sidecar: {valid, count, ...} header (64 words) followed by one 16-byte entry per group.
-    uint32_t* tileHist;             // large passes: [workgroup][1024 tiles] groups per tile -> (scan) groups of the tile in earlier workgroups
-    uint32_t* tileTotal;            // [1024 tiles]
+    uint32_t* tileHist;             // large passes: [workgroup][kNumTiles] groups per tile -> (scan) groups of the tile in earlier workgroups
+    uint32_t* tileTotal;            // [kNumTiles]
     uint16_t* tileOf;               // per entry
     uint2* lodSel;                  // per entry: {meshlets, first meshlet} of the LOD the instance was submitted at
     uint32_t* permHeader;
@@ -117,8 +117,10 @@ __global__ __launch_bounds__(256) void instanceCacheKernel(const BasePassInstanc
     }
 }
 
+// 16 x 16 screen tiles: on C3 the meshlet cull runs equally fast with 8 x 8, 16 x 16 and 32 x 32 (measured, profiles/r2/
+// experiments.md), and everything that walks the [workgroup][tile] histogram gets cheaper with fewer tiles.
 #ifndef TR_TILES_PER_AXIS
-#define TR_TILES_PER_AXIS 32
+#define TR_TILES_PER_AXIS 16
 #endif
 constexpr uint32_t kTilesPerAxis = TR_TILES_PER_AXIS;
 constexpr uint32_t kNumTiles = kTilesPerAxis * kTilesPerAxis;
@@ -128,7 +130,7 @@ constexpr uint32_t kPermHeaderWords = 64;
 #endif
 constexpr uint32_t kMinBinnedEntries = TR_MIN_BINNED;      // below this many list entries the processing order is left alone (device-side test)
 
-// Which 1/32 x 1/32 screen tile the instance's centre projects to.  Scheduling heuristic only
+// Which screen tile (kTilesPerAxis x kTilesPerAxis of them) the instance's centre projects to.  Scheduling heuristic only
 // (approximate reciprocal, no exactness requirement): it never influences an output value.
 __device__ __forceinline__ uint32_t screenTile(cm::F3 cv, float P00, float P11)
 {
@@ -222,9 +224,9 @@ __device__ __forceinline__ uint32_t classify(const InstanceCullArgs& a, uint32_t
 // counted the tile histogram and handed out the tile-run places with 2 x 440 k global atomics on C3, which paced both
 // kernels).  A workgroup of kBigThreads threads owns kBigChunk consecutive list entries:
 //   classify   per entry: the tests + LOD (classify<>), the word / block-local offset / tile / LOD selection to scratch;
-//              per workgroup: its sums and its tile histogram (LDS atomics) as row `block` of H[blocks][1024 tiles];
+//              per workgroup: its sums and its tile histogram (LDS atomics) as row `block` of H[blocks][tiles];
 //   scan       workgroup 0: exclusive scan of the workgroups' sums, final counters (what the reference's atomics
-//              leave), late-cull arguments; workgroups 1..64: sixteen tile columns of H each -> H[b][t] = groups
+//              leave), late-cull arguments; workgroups 1..: sixteen tile columns of H each -> H[b][t] = groups
 //              of tile t in workgroups < b (64 stripes of workgroups, two walks), tile totals T[t];
 //   emit       per workgroup: run starts = exclusive scan of T + its row of H, kept as LDS cursors; records in canonical
 //              order, tile-ordered resolved entries at cursor positions (LDS atomics: the order inside a
@@ -243,9 +245,9 @@ constexpr uint32_t kBigPerThread = TR_BIG_PER;
 constexpr uint32_t kScanThreads = 1024;
 constexpr uint32_t kBigChunk = kBigThreads * kBigPerThread;
 constexpr uint32_t kBigWaves = kBigThreads / 64;
-constexpr uint32_t kScanTileGroups = 64;                   // scan workgroups 1..64
-constexpr uint32_t kScanTilesPerGroup = kNumTiles / kScanTileGroups;     // 16
-constexpr uint32_t kScanStripes = kScanThreads / kScanTilesPerGroup;     // 64
+constexpr uint32_t kScanTilesPerGroup = kNumTiles < 16 ? kNumTiles : 16;  // tile columns per scan workgroup (64 contiguous bytes of a row)
+constexpr uint32_t kScanTileGroups = kNumTiles / kScanTilesPerGroup;      // scan workgroups 1..kScanTileGroups
+constexpr uint32_t kScanStripes = kScanThreads / kScanTilesPerGroup;      // 64 stripes of workgroups
 
 template <int LATE>
 __device__ __forceinline__ uint32_t activeBigBlocks(const InstanceCullArgs& a, uint32_t n)
@@ -451,13 +453,14 @@ __global__ __launch_bounds__(kBigThreads) void instanceEmitKernel(InstanceCullAr
         // run start of (this workgroup, tile) = groups of the tiles before it + groups of this tile in earlier workgroups
         uint32_t carry = 0;
         for (uint32_t base = 0; base < kNumTiles; base += kBigThreads) {
-            const uint32_t tot = a.tileTotal[base + tid];
+            const bool inRange = base + tid < kNumTiles;
+            const uint32_t tot = inRange ? a.tileTotal[base + tid] : 0u;
             const uint32_t inc = waveInclusiveScan(tot, lane);
             if (lane == 63) s_wave[wave] = inc;
             __syncthreads();
             uint32_t pre = 0, all = 0;
             for (uint32_t w = 0; w < kBigWaves; ++w) { if (w < wave) pre += s_wave[w]; all += s_wave[w]; }
-            s_cursor[base + tid] = carry + pre + inc - tot + a.tileHist[(uint64_t)blockIdx.x * kNumTiles + base + tid];
+            if (inRange) s_cursor[base + tid] = carry + pre + inc - tot + a.tileHist[(uint64_t)blockIdx.x * kNumTiles + base + tid];
             carry += all;
             __syncthreads();
         }
