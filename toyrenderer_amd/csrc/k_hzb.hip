@@ -117,7 +117,14 @@ __global__ __launch_bounds__(256) void hzbDepthTileKernel(const float* __restric
         int x0 = (int)__builtin_floorf(fx);
         const int x1 = min(max(x0 + 1, 0), (int)W - 1);
         x0 = min(max(x0, 0), (int)W - 1);
-#pragma unroll 4
+        const int xl = min(x0, (int)W - 2);                                           // base of the 8-byte load (W >= 2)
+        // All 32 loads of the thread's 16 texels are requested before the first result is stored (the stores to the HZB
+        // may alias the depth image as far as the compiler knows, so it would not move a load above them by itself).
+        struct __attribute__((packed, aligned(4))) Pair { float a, b; };
+        const bool wide = W >= 2u;               // the two texels of a row are neighbours (or the same one at a clamped edge):
+                                                 // ONE 8-byte load per row (dword-aligned) instead of two scalar loads
+        Pair v0[16], v1[16];
+#pragma unroll
         for (uint32_t it = 0; it < 16; ++it) {
             const uint32_t ly = it * 4 + (tid >> 6), y = ty * 64 + ly;
             const float v = ((float)y + 0.5f) / (float)oh;
@@ -125,8 +132,19 @@ __global__ __launch_bounds__(256) void hzbDepthTileKernel(const float* __restric
             int y0 = (int)__builtin_floorf(fy);
             const int y1 = min(max(y0 + 1, 0), (int)H - 1);
             y0 = min(max(y0, 0), (int)H - 1);
-            const float p = depth[(uint64_t)y0 * W + x0], q = depth[(uint64_t)y0 * W + x1];
-            const float r = depth[(uint64_t)y1 * W + x0], t = depth[(uint64_t)y1 * W + x1];
+            if (wide) {
+                v0[it] = *reinterpret_cast<const Pair*>(depth + (uint64_t)y0 * W + xl);
+                v1[it] = *reinterpret_cast<const Pair*>(depth + (uint64_t)y1 * W + xl);
+            } else {
+                v0[it] = { depth[(uint64_t)y0 * W + x0], depth[(uint64_t)y0 * W + x1] };
+                v1[it] = { depth[(uint64_t)y1 * W + x0], depth[(uint64_t)y1 * W + x1] };
+            }
+        }
+#pragma unroll
+        for (uint32_t it = 0; it < 16; ++it) {
+            const uint32_t ly = it * 4 + (tid >> 6), y = ty * 64 + ly;
+            const float p = !wide || x0 == xl ? v0[it].a : v0[it].b, q = wide && x1 == xl ? v0[it].a : v0[it].b;
+            const float r = !wide || x0 == xl ? v1[it].a : v1[it].b, t = wide && x1 == xl ? v1[it].a : v1[it].b;
             const _Float16 h = (_Float16)red4<MAX>(p, q, r, t);                       // R16_FLOAT store, RNE (Q10)
             m0[(uint64_t)y * ow + x] = h;
             s0[ly * 64 + lx] = (float)h;
