@@ -8,7 +8,13 @@ os.makedirs(dst, exist_ok=True)
 for f in ("final_bench.json", "final_bench_under_rocprof.json", "final_frame_timeline.txt", "final_kernel_stats.csv", "c4_animate_bench.json", "emulated_rank_share.txt"):
     shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 d = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_r2final", "g*", "*", "*counter_collection.csv"))):
+# gpurun merges every call's files into the local gpurun_out/: keep only the NEWEST collection of each counter group
+newest = {}
+for f in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_r2final", "g*", "*", "*counter_collection.csv")):
+    g = f.split(os.sep)[-3]
+    if g not in newest or os.path.getmtime(f) > os.path.getmtime(newest[g]):
+        newest[g] = f
+for f in sorted(newest.values()):
     for r in csv.DictReader(open(f)):
         if "meshletCullKernel" in r["Kernel_Name"]:
             d[r["Kernel_Name"][:86]][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
