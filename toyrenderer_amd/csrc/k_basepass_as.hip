@@ -161,10 +161,28 @@ __device__ __forceinline__ void issueMeshletLoads(char* slotLds /* wave-uniform 
     const char* pb = p + 16u * jb;
     const uint32_t ldsOff = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)slotLds;
     // nt: the 1.8 GB stream is read once and must not evict the HZB table and the per-record data from the L2s
+#ifndef TR_DMA_POLICY_ID
+#define TR_DMA_POLICY_ID 1       /* experiments (profiles/r2/experiments.md): cache policy of the stream */
+#endif
+#if TR_DMA_POLICY_ID == 0
+#define TR_DMA_POLICY ""
+#elif TR_DMA_POLICY_ID == 1
+#define TR_DMA_POLICY "nt"
+#elif TR_DMA_POLICY_ID == 2
+#define TR_DMA_POLICY "sc1"
+#elif TR_DMA_POLICY_ID == 3
+#define TR_DMA_POLICY "sc0 sc1"
+#elif TR_DMA_POLICY_ID == 4
+#define TR_DMA_POLICY "sc0 sc1 nt"
+#elif TR_DMA_POLICY_ID == 5
+#define TR_DMA_POLICY "sc0"
+#else
+#define TR_DMA_POLICY "sc1 nt"
+#endif
     asm volatile("s_mov_b32 m0, %2\n\t"
-                 "global_load_lds_dwordx4 %0, off nt\n\t"
+                 "global_load_lds_dwordx4 %0, off " TR_DMA_POLICY "\n\t"
                  "s_add_u32 m0, %2, 0x400\n\t"
-                 "global_load_lds_dwordx4 %1, off nt"
+                 "global_load_lds_dwordx4 %1, off " TR_DMA_POLICY
                  :: "v"(pa), "v"(pb), "s"(ldsOff) : "memory", "m0", "scc");
 }
 #define TR_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
