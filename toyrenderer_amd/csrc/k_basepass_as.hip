@@ -371,8 +371,12 @@ __global__ __launch_bounds__(kCullBlock) void meshletCullKernel(MeshletCullArgs 
                 // accepted at the near plane (:48-49): the tests are pure, so skipping a lookup whose result cannot
                 // matter changes nothing, and a third fewer scattered requests reach the L1 (the kernel's bottleneck).
                 const uint16_t* entry = reinterpret_cast<const uint16_t*>(a.quad.base) + oq.iq;
+#ifdef TR_NO_LOOKUP      /* experiment, results WRONG: what the kernel would cost if the lookups were free */
+                asm volatile("" : "+v"(footprintBits) : "v"(entry));
+#else
                 if (vis & !oq.accept)
                     asm volatile("global_load_ushort %0, %1, off" : "+v"(footprintBits) : "v"(entry) : "memory");
+#endif
             }
             if (OCCLUSION && !TABLE) {
                 os = cm::occTailTexel(q, cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_quadOff);
