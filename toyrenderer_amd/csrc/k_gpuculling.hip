@@ -541,6 +541,12 @@ __global__ __launch_bounds__(kBigThreads) void instanceEmitKernel(InstanceCullAr
 // processing order of the meshlet pass stays canonical: measured a wash at this size).
 constexpr uint32_t kFusedMaxEntries = 1u << 17;
 constexpr uint32_t kFusedMaxTiles = kFusedMaxEntries / kBlock;       // 512
+// The LATE pass takes this kernel whatever its capacity (up to 4096 tiles = 1 M list entries): its list is the late list,
+// typically an eighth of the capacity or less, its length is only known on the device, and its three-kernel form was a
+// chain of 30 us (6 + 18 + 6 on C3, the scan's dependent round trips stretched by the early list build running next to
+// them) for 100 k entries.  Workgroups past the list's end leave before they take a ticket, so the grid can cover the
+// capacity; the tile order of the meshlet cull is given up for the late pass (measured: worth nothing there).
+constexpr uint32_t kFusedLateMaxTiles = 4096;
 constexpr uint32_t kFusedStatusStride = 16;                          // 64-bit words per tile: one 128-byte line
 constexpr unsigned long long kFusedFlag = 1ull << 63, kFusedPoison = 1ull << 60;
 
@@ -556,12 +562,13 @@ __global__ __launch_bounds__(kBlock) void instanceFusedKernel(InstanceCullArgs a
     // the counters the pass continues from: read by every workgroup before any tile can finish the pass and rewrite them
     const uint32_t baseX = a.dispatchArgs[0];
     const uint32_t baseLate = LATE ? 0u : *a.lateCount;
-    for (;;) {
-        __syncthreads();                                                             // s_tile and the LDS sums are reused
+    // The grid covers the capacity (>= numTiles workgroups): exactly max(numTiles, 1) of them stay, each takes ONE ticket
+    // = one tile.  (An empty pass is closed by workgroup 0 as "tile 0".)
+    if (blockIdx.x >= (numTiles ? numTiles : 1u)) return;
+    {
         if (tid == 0) s_tile = atomicAdd(a.fusedTicket, 1u);
         __syncthreads();
         const uint32_t tile = s_tile;
-        if (tile >= numTiles && !(tile == 0 && numTiles == 0)) return;
         const uint32_t t = tile * kBlock + tid;
         uint32_t word = 0, tileUnused = 0;
         uint2 lodUnused;
@@ -648,7 +655,6 @@ __global__ __launch_bounds__(kBlock) void instanceFusedKernel(InstanceCullArgs a
             a.permHeader[0] = 0u;                                                        // canonical processing order
             a.permHeader[1] = X;
         }
-        if (numTiles == 0) return;
     }
 }
 
@@ -750,7 +756,7 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
     a.numInstances = (uint32_t)(instances->byteSize / sizeof(BasePassInstanceConstants));
     ctx.emit("instance_cache", [instances, meshData](hipStream_t s) { return trhip::instanceCacheLaunchBuild(instances, meshData, s); });
     static const bool noFused = getenv("TRHIP_NO_FUSED_INSTANCE") != nullptr;          // tests: the three-kernel path on small passes
-    const bool fusedPath = nMax <= kFusedMaxEntries && !noFused;
+    const bool fusedPath = (nMax <= kFusedMaxEntries || (LATE && (nMax + kBlock - 1) / kBlock <= kFusedLateMaxTiles)) && !noFused;
     a.numBlocks = fusedPath ? (nMax + kBlock - 1) / kBlock : (nMax + kBigChunk - 1) / kBigChunk;
     a.word = (uint32_t*)ctx.scratch((size_t)nMax * 4);
     a.localOff = (uint32_t*)ctx.scratch((size_t)nMax * 4);
@@ -784,13 +790,13 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
     }
 
     if (fusedPath) {
-        const size_t words = (size_t)kFusedMaxTiles * kFusedStatusStride * 2 + 4;
+        const size_t words = (size_t)a.numBlocks * kFusedStatusStride * 2 + 4;
         uint32_t* mem = (uint32_t*)ctx.scratch(words * 4);
         TRHIP_REQUIRE(mem, "%s: scratch allocation failed", ctx.shaderName);
         rc = ctx.cl->recordClearWords(mem, words, 0, true);
         if (rc != TRHIP_OK) return rc;
         a.fusedStatus = (unsigned long long*)mem;
-        a.fusedTicket = mem + kFusedMaxTiles * kFusedStatusStride * 2;
+        a.fusedTicket = mem + (size_t)a.numBlocks * kFusedStatusStride * 2;
         ctx.emit("fused", [a](hipStream_t s) {
             hipLaunchKernelGGL(instanceFusedKernel<LATE>, dim3(a.numBlocks), dim3(kBlock), 0, s, a);
             return trhip::launchStatus("instanceFusedKernel"); });
