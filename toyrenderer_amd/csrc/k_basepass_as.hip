@@ -115,7 +115,8 @@ struct MeshletCullArgs
     uint32_t* visibleList; uint32_t listCapacity;
     uint32_t* drawArgs;
     // scratch
-    uint32_t* batchSum;                           // per batch: visible meshlets -> exclusive prefix after scan
+    uint32_t* batchSum;                           // per batch of 64 groups: visible meshlets
+    uint32_t* superSum;                           // per 256 batches: visible meshlets -> exclusive prefix after the super scan
     uint32_t maxBatches;
     // optional processing order written by the instance pass into the record buffer's sidecar
     // (k_gpuculling.hip): {valid, count} header + a permutation of [0, count) sorted by screen tile
@@ -484,18 +485,49 @@ __global__ __launch_bounds__(kCullBlock) void meshletCullKernel(MeshletCullArgs 
 #endif
 }
 
-// Visible meshlets per batch of 64 consecutive records (canonical order): one wave per batch.
-__global__ __launch_bounds__(kBlock) void visCountKernel(MeshletCullArgs a)
+// Visible meshlets per batch of 64 consecutive records (canonical order): one wave per batch.  Two levels of sums -- per
+// batch and per "super" of 256 batches, a workgroup per super so that both are plain stores -- and a scan over the supers
+// only (visSuperScanKernel: 107 values on C3): the expansion finds a batch's list offset from the super's prefix + the
+// batches before it in its super (at most four loads per lane).  The single-workgroup scan over ALL batches was 20 us on
+// C3 (27 k batches), during which the expansion it delayed ran into the late meshlet cull.  (Per-super sums by
+// device-scope atomics instead: 27 k atomics on 107 addresses took 100 us and stalled the HZB build next to them.)
+constexpr uint32_t kSuperShift = 8;
+constexpr uint32_t kSuperBatches = 1u << kSuperShift;
+constexpr uint32_t kCountThreads = 1024;
+constexpr uint32_t kCountWaves = kCountThreads / 64;
+__global__ __launch_bounds__(kCountThreads) void visCountKernel(MeshletCullArgs a)
 {
+    __shared__ uint32_t s_part[kCountWaves];
     const uint32_t G = groupCount(a);
     const uint32_t numBatches = (G + kBatch - 1) / kBatch;
+    const uint32_t numSupers = (numBatches + kSuperBatches - 1) >> kSuperShift;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t batch = blockIdx.x * kWaves + wave; batch < numBatches; batch += gridDim.x * kWaves) {
-        const uint32_t g = batch * kBatch + lane;
-        uint32_t pc = g < G ? (uint32_t)__popc(a.visMask[g]) : 0u;
+    constexpr uint32_t kPerWave = kSuperBatches / kCountWaves;                       // 16 batches
+    for (uint32_t sb = blockIdx.x; sb < numSupers; sb += gridDim.x) {
+        const uint32_t b0 = (sb << kSuperShift) + wave * kPerWave;
+        uint32_t pc[kPerWave];
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) pc += __shfl_xor(pc, d);
-        if (lane == 0) a.batchSum[batch] = pc;
+        for (uint32_t i = 0; i < kPerWave; ++i) {
+            const uint32_t g = (b0 + i) * kBatch + lane;
+            pc[i] = g < G ? (uint32_t)__popc(a.visMask[g]) : 0u;
+        }
+        uint32_t mine = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < kPerWave; ++i) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) pc[i] += __shfl_xor(pc[i], d);
+            if (lane == 0 && b0 + i < numBatches) a.batchSum[b0 + i] = pc[i];
+            mine += pc[i];
+        }
+        __syncthreads();                                                             // s_part consumed by the previous round
+        if (lane == 0) s_part[wave] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < kCountWaves; ++w) total += s_part[w];
+            a.superSum[sb] = total;
+        }
     }
 }
 
@@ -509,49 +541,30 @@ __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v, uint32_t lane)
     return v;
 }
 
-// One block: exclusive scan of the batch sums -> list offsets; total -> drawArgs.
-// Tiles of 1024 with a carry; a tile = wave scans + one LDS exchange (two barriers).  The loads of 16
-// tiles are issued together so that their latency is paid once per 16 tiles, not once per tile.
-__global__ __launch_bounds__(1024) void visScanKernel(MeshletCullArgs a)
+// One workgroup: exclusive scan of the super sums in place; the total replaces DispatchMesh(numVisible,1,1) summed over
+// groups (basepass.hlsl:120-121).
+__global__ __launch_bounds__(1024) void visSuperScanKernel(MeshletCullArgs a)
 {
-    __shared__ uint32_t s_wave[2][16];
+    __shared__ uint32_t s_wave[16];
     const uint32_t G = groupCount(a);
     const uint32_t numBatches = (G + kBatch - 1) / kBatch;
+    const uint32_t numSupers = (numBatches + kSuperBatches - 1) >> kSuperShift;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t carry = 0, flip = 0;
-    for (uint32_t base = 0; base < numBatches; base += 16 * 1024) {
-        uint32_t vals[16];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < numSupers; base += 1024u) {
+        const uint32_t i = base + tid;
+        const uint32_t v = i < numSupers ? a.superSum[i] : 0u;
+        const uint32_t inc = waveInclusiveScan(v, lane);
+        __syncthreads();
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t pre = 0, all = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < 16; ++k) {
-            const uint32_t i = base + k * 1024 + tid;
-            vals[k] = i < numBatches ? a.batchSum[i] : 0u;
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < 16; ++k) {
-            const uint32_t i = base + k * 1024 + tid;
-            if (base + k * 1024 < numBatches) {                                       // uniform
-                const uint32_t v = vals[k];
-                const uint32_t inc = waveInclusiveScan(v, lane);
-                if (lane == 63) s_wave[flip][wave] = inc;
-                __syncthreads();
-                uint32_t pre = 0, tot = 0;
-#pragma unroll
-                for (uint32_t w = 0; w < 16; ++w) {
-                    const uint32_t x = s_wave[flip][w];
-                    if (w < wave) pre += x;
-                    tot += x;
-                }
-                if (i < numBatches) a.batchSum[i] = carry + pre + inc - v;
-                carry += tot;
-                flip ^= 1u;                                                           // double-buffered exchange: one barrier per tile
-            }
-        }
+        for (uint32_t w = 0; w < 16; ++w) { if (w < wave) pre += s_wave[w]; all += s_wave[w]; }
+        if (i < numSupers) a.superSum[i] = carry + pre + inc - v;
+        carry += all;
     }
-    if (tid == 0) {
-        a.drawArgs[0] = carry;         // replaces DispatchMesh(numVisible,1,1) summed over groups (basepass.hlsl:120-121)
-        a.drawArgs[1] = 1;
-        a.drawArgs[2] = 1;
-    }
+    if (tid == 0) { a.drawArgs[0] = carry; a.drawArgs[1] = 1; a.drawArgs[2] = 1; }
 }
 
 // Ordered compaction, one wave per batch: lane l holds the mask of record l, a wave scan gives
@@ -569,8 +582,15 @@ __global__ __launch_bounds__(kBlock) void visExpandKernel(MeshletCullArgs a)
     for (uint32_t batch = blockIdx.x * kWaves + wave; batch < numBatches; batch += gridDim.x * kWaves) {
         const uint32_t g0 = batch * kBatch;
         const uint32_t mask = g0 + lane < G ? a.visMask[g0 + lane] : 0u;
+        // list offset of the batch: its super's prefix + the batches before it in its super
+        const uint32_t sb = batch >> kSuperShift;
+        uint32_t before = 0;
+        for (uint32_t j = (sb << kSuperShift) + lane; j < batch; j += 64u) before += a.batchSum[j];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
+        before += a.superSum[sb];
         const uint32_t pc = (uint32_t)__popc(mask);
-        const uint32_t exc = waveInclusiveScan(pc, lane) - pc + a.batchSum[batch];
+        const uint32_t exc = waveInclusiveScan(pc, lane) - pc + before;
         mo[lane] = make_uint2(mask, exc);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1001,7 +1021,7 @@ __global__ __launch_bounds__(256) void shardUnpackKernel(ShardUnpackArgs a)
     }
 }
 
-// Launches the ordered-list build (count -> scan -> expand) over a mask array.  side: on the device's side
+// Launches the ordered-list build (count -> scan of the 256-batch sums -> expand; one compact launch for small passes) over a mask array.  side: on the device's side
 // stream -- nothing later in a frame consumes the list, so it overlaps the passes that follow (HZB build,
 // late phase); the back end joins it before any command that touches the same buffers and at the end of
 // the submission (trhip_internal.h).
@@ -1034,12 +1054,13 @@ void emitListBuild(const trhip::DispatchCtx& ctx, const MeshletCullArgs& a, cons
     if (gridSmall > needBlocks) gridSmall = needBlocks;
     if (gridSmall == 0) gridSmall = 1;
     const std::string p = prefix;
-    emit(p + "count", [a, gridSmall](hipStream_t s) {
-        hipLaunchKernelGGL(visCountKernel, dim3(gridSmall), dim3(kBlock), 0, s, a);
+    const uint32_t supers = (a.maxBatches >> kSuperShift) + 1u;
+    emit(p + "count", [a, supers](hipStream_t s) {
+        hipLaunchKernelGGL(visCountKernel, dim3(supers), dim3(kCountThreads), 0, s, a);
         return trhip::launchStatus("visCountKernel"); });
     emit(p + "scan", [a](hipStream_t s) {
-        hipLaunchKernelGGL(visScanKernel, dim3(1), dim3(1024), 0, s, a);
-        return trhip::launchStatus("visScanKernel"); });
+        hipLaunchKernelGGL(visSuperScanKernel, dim3(1), dim3(1024), 0, s, a);
+        return trhip::launchStatus("visSuperScanKernel"); });
     emit(p + "expand", [a, gridSmall](hipStream_t s) {
         hipLaunchKernelGGL(visExpandKernel, dim3(gridSmall), dim3(kBlock), 0, s, a);
         return trhip::launchStatus("visExpandKernel"); });
@@ -1132,6 +1153,11 @@ int recordASMain(trhip::DispatchCtx& ctx)
     a.batchSum = (uint32_t*)(a.recordCapacity >= (1u << 19) ? ctx.scratchSide((size_t)a.maxBatches * 4)   // only the list build uses it
                                                             : ctx.scratch((size_t)a.maxBatches * 4));
     TRHIP_REQUIRE(a.batchSum, "%s: scratch allocation failed", ctx.shaderName);
+    {
+        const size_t supers = (a.maxBatches >> kSuperShift) + 1u;
+        a.superSum = (uint32_t*)(a.recordCapacity >= (1u << 19) ? ctx.scratchSide(supers * 4) : ctx.scratch(supers * 4));
+        TRHIP_REQUIRE(a.superSum, "%s: scratch allocation failed", ctx.shaderName);
+    }
 
     // Persistent grid: the group count lives on the device (indirect), so launch enough
     // workgroups to fill the chip and let them stride over the chunks.
@@ -1284,7 +1310,10 @@ int recordUnpackShards(trhip::DispatchCtx& ctx)
         l.drawArgs = a.args[s] + 4;
         l.maxBatches = (l.recordCapacity + kBatch - 1) / kBatch;
         l.batchSum = (uint32_t*)ctx.scratch((size_t)l.maxBatches * 4);
-        TRHIP_REQUIRE(l.batchSum, "%s: scratch allocation failed", ctx.shaderName);
+        const size_t supers = (l.maxBatches >> kSuperShift) + 1u;
+        l.superSum = (uint32_t*)ctx.scratch(supers * 4);
+        TRHIP_REQUIRE(l.batchSum && l.superSum, "%s: scratch allocation failed", ctx.shaderName);
+
     }
     uint32_t grid = ctx.computeUnits() * 4u;
     const uint64_t need = (copyWords + 255u) / 256u;
