@@ -197,80 +197,34 @@ public:
         // multi-GPU: a rank without alpha-mask ids still walks the alpha-mask passes when another rank has some (it posts
         // the in-frame collectives with a zero count, see GPUCulling)
         m_NumSlotsThisFrame = BucketPresentAnywhere(true) ? (uint32_t)kNumPassSlots : 2u;
+        // The pass's transient buffers (BasePassRenderers.cpp:235-293), one line each: {handle, name, element, count, kind}.
+        // Arguments buffers are indirect-argument resources, everything else a shader resource; all are UAV-capable.
+        enum Kind { kData, kArgs };
+        auto transient = [&renderGraph](RenderGraph::ResourceHandle& handle, const char* name, uint32_t elementBytes, uint64_t elements, Kind kind) {
+            nvrhi::BufferDesc desc;
+            desc.debugName = name;
+            desc.structStride = elementBytes;
+            desc.byteSize = elementBytes * elements;
+            desc.canHaveUAVs = true;
+            desc.isDrawIndirectArgs = kind == kArgs;
+            desc.initialState = kind == kArgs ? nvrhi::ResourceStates::IndirectArgument : nvrhi::ResourceStates::ShaderResource;
+            renderGraph.CreateTransientResource(handle, desc);
+        };
         for (uint32_t slot = 0; slot < m_NumSlotsThisFrame; ++slot) {
-            {
-                nvrhi::BufferDesc desc;                                       // :235-243
-                desc.byteSize = sizeof(MeshletAmplificationData) * (uint64_t)maxGroups;
-                desc.structStride = sizeof(MeshletAmplificationData);
-                desc.canHaveUAVs = true;
-                desc.initialState = nvrhi::ResourceStates::ShaderResource;
-                desc.debugName = "MeshletAmplificationDataBuffer";
-                renderGraph.CreateTransientResource(m_MeshletAmplificationDataBufferRDGBufferHandle[slot], desc);
-            }
-            {
-                nvrhi::BufferDesc desc;                                       // :245-254 (+ 4th word: valid records, ShaderInterop.h DispatchIndirectArgumentsEx)
-                desc.byteSize = sizeof(DispatchIndirectArgumentsEx);
-                desc.structStride = sizeof(DispatchIndirectArgumentsEx);
-                desc.canHaveUAVs = true;
-                desc.isDrawIndirectArgs = true;
-                desc.initialState = nvrhi::ResourceStates::IndirectArgument;
-                desc.debugName = "MeshletDispatchArgumentsBuffer";
-                renderGraph.CreateTransientResource(m_MeshletDispatchArgumentsBufferRDGBufferHandle[slot], desc);
-            }
-            {
-                nvrhi::BufferDesc desc;                                       // replaces MeshletPayload (ShaderInterop.h:200-205)
-                desc.byteSize = sizeof(uint32_t) * (uint64_t)maxGroups;
-                desc.structStride = sizeof(uint32_t);
-                desc.canHaveUAVs = true;
-                desc.initialState = nvrhi::ResourceStates::ShaderResource;
-                desc.debugName = "MeshletVisibilityMaskBuffer";
-                renderGraph.CreateTransientResource(m_MeshletVisibilityMaskBufferRDGBufferHandle[slot], desc);
-                desc.byteSize = sizeof(uint32_t) * (uint64_t)maxGroups * kNumThreadsPerWave;
-                desc.debugName = "VisibleMeshletListBuffer";
-                renderGraph.CreateTransientResource(m_VisibleMeshletListBufferRDGBufferHandle[slot], desc);
-            }
-            {
-                nvrhi::BufferDesc desc;                                       // replaces DispatchMesh(numVisible,1,1) (basepass.hlsl:120-121)
-                desc.byteSize = sizeof(DispatchIndirectArguments);
-                desc.structStride = sizeof(DispatchIndirectArguments);
-                desc.canHaveUAVs = true;
-                desc.isDrawIndirectArgs = true;
-                desc.initialState = nvrhi::ResourceStates::IndirectArgument;
-                desc.debugName = "VisibleMeshletDrawArgsBuffer";
-                renderGraph.CreateTransientResource(m_VisibleMeshletDrawArgsBufferRDGBufferHandle[slot], desc);
-            }
+            transient(m_MeshletAmplificationDataBufferRDGBufferHandle[slot], "MeshletAmplificationDataBuffer", sizeof(MeshletAmplificationData), maxGroups, kData);   // :235-243
+            // :245-254, + a 4th word: the valid records (ShaderInterop.h DispatchIndirectArgumentsEx)
+            transient(m_MeshletDispatchArgumentsBufferRDGBufferHandle[slot], "MeshletDispatchArgumentsBuffer", sizeof(DispatchIndirectArgumentsEx), 1, kArgs);
+            // what replaces MeshletPayload (ShaderInterop.h:200-205) and DispatchMesh(numVisible,1,1) (basepass.hlsl:120-121)
+            transient(m_MeshletVisibilityMaskBufferRDGBufferHandle[slot], "MeshletVisibilityMaskBuffer", sizeof(uint32_t), maxGroups, kData);
+            transient(m_VisibleMeshletListBufferRDGBufferHandle[slot], "VisibleMeshletListBuffer", sizeof(uint32_t), (uint64_t)maxGroups * kNumThreadsPerWave, kData);
+            transient(m_VisibleMeshletDrawArgsBufferRDGBufferHandle[slot], "VisibleMeshletDrawArgsBuffer", sizeof(DispatchIndirectArguments), 1, kArgs);
         }
 
         if (m_bDoOcclusionCulling) {                                          // :256-293
             m_SPDHelper.CreateTransientResources(renderGraph);
-            {
-                nvrhi::BufferDesc desc;
-                desc.byteSize = sizeof(DispatchIndirectArguments);
-                desc.structStride = sizeof(DispatchIndirectArguments);
-                desc.canHaveUAVs = true;
-                desc.isDrawIndirectArgs = true;
-                desc.initialState = nvrhi::ResourceStates::IndirectArgument;
-                desc.debugName = "LateCullDispatchIndirectArgs";
-                renderGraph.CreateTransientResource(m_LateCullDispatchIndirectArgsRDGBufferHandle, desc);
-            }
-            {
-                nvrhi::BufferDesc desc;
-                desc.byteSize = sizeof(uint32_t);
-                desc.structStride = sizeof(uint32_t);
-                desc.canHaveUAVs = true;
-                desc.initialState = nvrhi::ResourceStates::ShaderResource;
-                desc.debugName = "LateCullInstanceCountBuffer";
-                renderGraph.CreateTransientResource(m_LateCullInstanceCountBufferRDGBufferHandle, desc);
-            }
-            {
-                nvrhi::BufferDesc desc;
-                desc.byteSize = sizeof(uint32_t) * (uint64_t)nbInstances;
-                desc.structStride = sizeof(uint32_t);
-                desc.canHaveUAVs = true;
-                desc.initialState = nvrhi::ResourceStates::ShaderResource;
-                desc.debugName = "LateCullInstanceIDsBuffer";
-                renderGraph.CreateTransientResource(m_LateCullInstanceIDsBufferRDGBufferHandle, desc);
-            }
+            transient(m_LateCullDispatchIndirectArgsRDGBufferHandle, "LateCullDispatchIndirectArgs", sizeof(DispatchIndirectArguments), 1, kArgs);
+            transient(m_LateCullInstanceCountBufferRDGBufferHandle, "LateCullInstanceCountBuffer", sizeof(uint32_t), 1, kData);
+            transient(m_LateCullInstanceIDsBufferRDGBufferHandle, "LateCullInstanceIDsBuffer", sizeof(uint32_t), nbInstances, kData);
         }
         return true;
     }
@@ -312,74 +266,63 @@ public:
             }
         }
 
-        const uint32_t forcedMeshLOD = (g_Scene->m_ForceMeshLOD >= 0) ? (uint32_t)g_Scene->m_ForceMeshLOD : kInvalidMeshLOD;   // :334
+        using Item = nvrhi::BindingSetItem;
+        const View& view = g_Scene->m_View;
+        GPUCullingPassConstants k{};                                          // :334-347
+        k.m_NbInstances = nbInstances;
+        k.m_CullingFlags = m_CullingFlags;
+        k.m_Frustum = m_CullingFrustum;
+        k.m_HZBDimensions = m_HZBDimensions;
+        k.m_WorldToView = view.m_CullingWorldToView;
+        k.m_PrevWorldToView = view.m_CullingPrevWorldToView;
+        k.m_NearPlane = view.m_ZNearP;
+        k.m_P00 = view.m_ViewToClip.m[0][0];
+        k.m_P11 = view.m_ViewToClip.m[1][1];
+        k.m_ForcedMeshLOD = g_Scene->m_ForceMeshLOD >= 0 ? (uint32_t)g_Scene->m_ForceMeshLOD : kInvalidMeshLOD;
+        k.m_MeshLODTarget = (2.0f / k.m_P11) * (1.0f / (float)g_Graphic.m_RenderResolution.y);
 
-        GPUCullingPassConstants passParameters{};                             // :336-347
-        passParameters.m_NbInstances = nbInstances;
-        passParameters.m_CullingFlags = m_CullingFlags;
-        passParameters.m_Frustum = m_CullingFrustum;
-        passParameters.m_HZBDimensions = m_HZBDimensions;
-        passParameters.m_WorldToView = g_Scene->m_View.m_CullingWorldToView;
-        passParameters.m_PrevWorldToView = g_Scene->m_View.m_CullingPrevWorldToView;
-        passParameters.m_NearPlane = g_Scene->m_View.m_ZNearP;
-        passParameters.m_P00 = g_Scene->m_View.m_ViewToClip.m[0][0];
-        passParameters.m_P11 = g_Scene->m_View.m_ViewToClip.m[1][1];
-        passParameters.m_ForcedMeshLOD = forcedMeshLOD;
-        passParameters.m_MeshLODTarget = (2.0f / g_Scene->m_View.m_ViewToClip.m[1][1]) * (1.0f / (float)g_Graphic.m_RenderResolution.y);
-
-        nvrhi::BufferHandle passConstantBuffer = g_Graphic.CreateConstantBuffer(commandList, passParameters);   // :349
-
-        nvrhi::BindingSetDesc bindingSetDesc;                                 // :351-362
-        bindingSetDesc.bindings = {
-            nvrhi::BindingSetItem::ConstantBuffer(0, passConstantBuffer),
-            nvrhi::BindingSetItem::StructuredBuffer_SRV(0, g_Scene->m_InstanceConstsBuffer),
-            nvrhi::BindingSetItem::StructuredBuffer_SRV(1, bAlphaMaskPrimitives ? g_Scene->m_AlphaMaskInstanceIDsBuffer : g_Scene->m_OpaqueInstanceIDsBuffer),
-            nvrhi::BindingSetItem::StructuredBuffer_SRV(2, g_Graphic.m_GlobalMeshDataBuffer),
-            nvrhi::BindingSetItem::Texture_SRV(3, m_bDoOcclusionCulling ? g_Scene->m_HZB : g_CommonResources.BlackTexture),
-            nvrhi::BindingSetItem::StructuredBuffer_UAV(0, meshletAmplificationDataBuffer),
-            nvrhi::BindingSetItem::StructuredBuffer_UAV(1, meshletDispatchArgumentsBuffer),
-            nvrhi::BindingSetItem::StructuredBuffer_UAV(2, lateCullInstanceCountBuffer),
-            nvrhi::BindingSetItem::StructuredBuffer_UAV(3, lateCullInstanceIDsBuffer),
-            nvrhi::BindingSetItem::Sampler(0, g_CommonResources.LinearClampMinReductionSampler)
+        // one pass description for the (direct) early and the (indirect) late dispatch (:349-375, :392-402)
+        Graphic::ComputePassParams cull;
+        cull.m_CommandList = commandList;
+        cull.m_ShaderName = bLateCull ? "gpuculling_CS_GPUCulling LATE_CULL=1" : "gpuculling_CS_GPUCulling LATE_CULL=0";
+        cull.m_BindingSetDesc.bindings = {
+            Item::ConstantBuffer(0, g_Graphic.CreateConstantBuffer(commandList, k)),
+            Item::Sampler(0, g_CommonResources.LinearClampMinReductionSampler),
+            Item::StructuredBuffer_SRV(0, g_Scene->m_InstanceConstsBuffer),
+            Item::StructuredBuffer_SRV(1, bAlphaMaskPrimitives ? g_Scene->m_AlphaMaskInstanceIDsBuffer : g_Scene->m_OpaqueInstanceIDsBuffer),
+            Item::StructuredBuffer_SRV(2, g_Graphic.m_GlobalMeshDataBuffer),
+            Item::Texture_SRV(3, m_bDoOcclusionCulling ? g_Scene->m_HZB : g_CommonResources.BlackTexture),
+            Item::StructuredBuffer_UAV(0, meshletAmplificationDataBuffer),
+            Item::StructuredBuffer_UAV(1, meshletDispatchArgumentsBuffer),
+            Item::StructuredBuffer_UAV(2, lateCullInstanceCountBuffer),
+            Item::StructuredBuffer_UAV(3, lateCullInstanceIDsBuffer),
         };
 
-        const std::string shaderName = "gpuculling_CS_GPUCulling LATE_CULL=" + std::to_string(bLateCull ? 1 : 0);   // :364
-
         if (!bLateCull) {
-            Graphic::ComputePassParams computePassParams;                     // :367-375
-            computePassParams.m_CommandList = commandList;
-            computePassParams.m_ShaderName = shaderName;
-            computePassParams.m_BindingSetDesc = bindingSetDesc;
-            computePassParams.m_DispatchGroupSize = ComputeShaderUtils::GetGroupCount(nbInstances, kNumThreadsPerWave);
-            g_Graphic.AddComputePass(computePassParams);
+            cull.m_DispatchGroupSize = ComputeShaderUtils::GetGroupCount(nbInstances, kNumThreadsPerWave);
+            g_Graphic.AddComputePass(cull);
 
-            if (m_bDoOcclusionCulling) {                                      // :377-389
-                bindingSetDesc.bindings = {
-                    nvrhi::BindingSetItem::StructuredBuffer_SRV(0, lateCullInstanceCountBuffer),
-                    nvrhi::BindingSetItem::StructuredBuffer_UAV(0, lateCullDispatchIndirectArgsBuffer)
-                };
-                computePassParams.m_ShaderName = "gpuculling_CS_BuildLateCullIndirectArgs";
-                computePassParams.m_BindingSetDesc = bindingSetDesc;
-                computePassParams.m_DispatchGroupSize = Vector3U{ 1, 1, 1 };
-                g_Graphic.AddComputePass(computePassParams);
+            if (m_bDoOcclusionCulling) {                                      // :377-389: the late dispatch's size from the late count
+                Graphic::ComputePassParams lateArgs;
+                lateArgs.m_CommandList = commandList;
+                lateArgs.m_ShaderName = "gpuculling_CS_BuildLateCullIndirectArgs";
+                lateArgs.m_DispatchGroupSize = Vector3U{ 1, 1, 1 };
+                lateArgs.m_BindingSetDesc.bindings = { Item::StructuredBuffer_SRV(0, lateCullInstanceCountBuffer), Item::StructuredBuffer_UAV(0, lateCullDispatchIndirectArgsBuffer) };
+                g_Graphic.AddComputePass(lateArgs);
                 // multi-GPU: the late-list length is final from here on -- the exchange starts now and has the whole
                 // early meshlet cull to complete (trhost.h)
                 if (g_ShardLateExchange.fn)
                     commandList->hostCallback(&ShardLateTrampoline<0>, &PrepareShardLateCall(bAlphaMaskPrimitives, lateCullInstanceCountBuffer.Get()));
             }
-        } else if (m_bDoOcclusionCulling) {                                   // :392-402
+        } else if (m_bDoOcclusionCulling) {
             if (g_ShardLateExchange.fn) {
                 // multi-GPU: the late dispatch size rule sees the whole scene's late list (trhost.h)
                 ShardLateCall& call = PrepareShardLateCall(bAlphaMaskPrimitives, lateCullInstanceCountBuffer.Get());
                 commandList->hostCallback(&ShardLateTrampoline<1>, &call);
-                bindingSetDesc.bindings.push_back(nvrhi::BindingSetItem::StructuredBuffer_SRV(4, call.info));
+                cull.m_BindingSetDesc.bindings.push_back(Item::StructuredBuffer_SRV(4, call.info));
             }
-            Graphic::ComputePassParams computePassParams;
-            computePassParams.m_CommandList = commandList;
-            computePassParams.m_ShaderName = shaderName;
-            computePassParams.m_BindingSetDesc = bindingSetDesc;
-            computePassParams.m_IndirectArgsBuffer = lateCullDispatchIndirectArgsBuffer;
-            g_Graphic.AddComputePass(computePassParams);
+            cull.m_IndirectArgsBuffer = lateCullDispatchIndirectArgsBuffer;
+            g_Graphic.AddComputePass(cull);
         }
         m_LastLateCullInstanceCountBuffer = lateCullInstanceCountBuffer;
         m_LastLateCullDispatchIndirectArgsBuffer = lateCullDispatchIndirectArgsBuffer;
@@ -400,43 +343,39 @@ public:
         nvrhi::BufferHandle visibleListBuffer = renderGraph.GetBuffer(m_VisibleMeshletListBufferRDGBufferHandle[slot]);
         nvrhi::BufferHandle visibleDrawArgsBuffer = renderGraph.GetBuffer(m_VisibleMeshletDrawArgsBufferRDGBufferHandle[slot]);
 
-        uint32_t finalCullingFlags = m_CullingFlags;
-        // assume alpha mask primitives are double-sided too, & ignore cone culling (:436-442, Q8)
-        if (bAlphaMaskPrimitives) finalCullingFlags &= ~kCullingFlagMeshletConeCullingEnable;
-
-        BasePassConstants basePassConstants{};                                // :445-458 (culling-relevant members)
-        basePassConstants.m_WorldToView = g_Scene->m_View.m_CullingWorldToView;
+        using Item = nvrhi::BindingSetItem;
+        const View& view = g_Scene->m_View;
+        BasePassConstants basePassConstants{};                                // :436-458 (the culling-relevant members)
+        basePassConstants.m_WorldToView = view.m_CullingWorldToView;
         basePassConstants.m_Frustum = m_CullingFrustum;
-        basePassConstants.m_CullingFlags = finalCullingFlags;
+        // alpha-mask primitives count as double-sided: no cone culling for them (:436-442, Q8)
+        basePassConstants.m_CullingFlags = bAlphaMaskPrimitives ? (m_CullingFlags & ~kCullingFlagMeshletConeCullingEnable) : m_CullingFlags;
         basePassConstants.m_HZBDimensions = m_HZBDimensions;
-        basePassConstants.m_P00 = g_Scene->m_View.m_ViewToClip.m[0][0];
-        basePassConstants.m_P11 = g_Scene->m_View.m_ViewToClip.m[1][1];
-        basePassConstants.m_NearPlane = g_Scene->m_View.m_ZNearP;
+        basePassConstants.m_P00 = view.m_ViewToClip.m[0][0];
+        basePassConstants.m_P11 = view.m_ViewToClip.m[1][1];
+        basePassConstants.m_NearPlane = view.m_ZNearP;
         basePassConstants.m_OutputResolution = g_Graphic.m_RenderResolution;
 
-        nvrhi::BufferHandle passConstantBuffer = g_Graphic.CreateConstantBuffer(commandList, basePassConstants);   // :460
-
-        nvrhi::BindingSetDesc bindingSetDesc;                                 // :463-479 (vertex / material / index SRVs t1,t3,t5,t6 feed MS/PS only)
-        bindingSetDesc.bindings = {
-            nvrhi::BindingSetItem::ConstantBuffer(0, passConstantBuffer),
-            nvrhi::BindingSetItem::StructuredBuffer_SRV(0, g_Scene->m_InstanceConstsBuffer),
-            nvrhi::BindingSetItem::StructuredBuffer_SRV(2, g_Graphic.m_GlobalMeshDataBuffer),
-            nvrhi::BindingSetItem::StructuredBuffer_SRV(4, g_Graphic.m_GlobalMeshletDataBuffer),
-            nvrhi::BindingSetItem::StructuredBuffer_SRV(7, meshletAmplificationDataBuffer),
-            nvrhi::BindingSetItem::Texture_SRV(8, m_bDoOcclusionCulling ? g_Scene->m_HZB : g_CommonResources.BlackTexture),
-            nvrhi::BindingSetItem::Sampler(4, g_CommonResources.LinearClampMinReductionSampler),
-            nvrhi::BindingSetItem::StructuredBuffer_UAV(0, visMaskBuffer),
-            nvrhi::BindingSetItem::StructuredBuffer_UAV(1, visibleListBuffer),
-            nvrhi::BindingSetItem::StructuredBuffer_UAV(2, visibleDrawArgsBuffer),
+        // :460-502: PSODesc.AS = "basepass_AS_Main LATE_CULL=%d", dispatchMeshIndirect(0) on meshletDispatchArgumentsBuffer.
+        // Of the reference's binding set the amplification stage reads b0, t0, t2, t4, t7, t8, s4 (t1, t3, t5, t6 feed the
+        // mesh / pixel stages); u0..u2 are this build's outputs.
+        Graphic::ComputePassParams amplification;
+        amplification.m_CommandList = commandList;
+        amplification.m_ShaderName = bIsLateCull ? "basepass_AS_Main LATE_CULL=1" : "basepass_AS_Main LATE_CULL=0";
+        amplification.m_IndirectArgsBuffer = meshletDispatchArgumentsBuffer;
+        amplification.m_BindingSetDesc.bindings = {
+            Item::ConstantBuffer(0, g_Graphic.CreateConstantBuffer(commandList, basePassConstants)),
+            Item::Sampler(4, g_CommonResources.LinearClampMinReductionSampler),
+            Item::StructuredBuffer_SRV(0, g_Scene->m_InstanceConstsBuffer),
+            Item::StructuredBuffer_SRV(2, g_Graphic.m_GlobalMeshDataBuffer),
+            Item::StructuredBuffer_SRV(4, g_Graphic.m_GlobalMeshletDataBuffer),
+            Item::StructuredBuffer_SRV(7, meshletAmplificationDataBuffer),
+            Item::Texture_SRV(8, m_bDoOcclusionCulling ? g_Scene->m_HZB : g_CommonResources.BlackTexture),
+            Item::StructuredBuffer_UAV(0, visMaskBuffer),
+            Item::StructuredBuffer_UAV(1, visibleListBuffer),
+            Item::StructuredBuffer_UAV(2, visibleDrawArgsBuffer),
         };
-
-        // :485-502: PSODesc.AS = "basepass_AS_Main LATE_CULL=%d"; dispatchMeshIndirect(0) on meshletDispatchArgumentsBuffer
-        Graphic::ComputePassParams computePassParams;
-        computePassParams.m_CommandList = commandList;
-        computePassParams.m_ShaderName = "basepass_AS_Main LATE_CULL=" + std::to_string(bIsLateCull ? 1 : 0);
-        computePassParams.m_BindingSetDesc = bindingSetDesc;
-        computePassParams.m_IndirectArgsBuffer = meshletDispatchArgumentsBuffer;
-        g_Graphic.AddComputePass(computePassParams);
+        g_Graphic.AddComputePass(amplification);
 
         if (g_Scene->m_bRasterDepth) {
             // The mesh + depth stages of the same DispatchMeshIndirect (basepass.hlsl:124-188, PSO :481-495), depth only:
@@ -529,12 +468,7 @@ public:
 
         m_HZBDimensions = m_bDoOcclusionCulling ? Vector2U{ g_Scene->m_HZB->getDesc().width, g_Scene->m_HZB->getDesc().height } : Vector2U{ 1, 1 };   // :555
 
-        Matrix projectionT = Transpose(g_Scene->m_View.m_ViewToClip);                               // :557-563
-        Vector4 frustumX = Vector4{ projectionT.m[3][0] + projectionT.m[0][0], projectionT.m[3][1] + projectionT.m[0][1], projectionT.m[3][2] + projectionT.m[0][2], projectionT.m[3][3] + projectionT.m[0][3] };
-        Vector4 frustumY = Vector4{ projectionT.m[3][0] + projectionT.m[1][0], projectionT.m[3][1] + projectionT.m[1][1], projectionT.m[3][2] + projectionT.m[1][2], projectionT.m[3][3] + projectionT.m[1][3] };
-        frustumX = Normalize(frustumX);
-        frustumY = Normalize(frustumY);
-        m_CullingFrustum = Vector4{ frustumX.x, frustumX.z, frustumY.y, frustumY.z };
+        m_CullingFrustum = CullingFrustumOf(g_Scene->m_View.m_ViewToClip);                           // :557-563
 
         // Where GenerateHZB finds the frame's depth: the depth attachment the rasteriser wrote -- or, when nothing rasterises
         // (the stand-in of the culling benchmarks and tests), the uploaded depth image itself.  (Round 1 copied the image

@@ -16,118 +16,108 @@ using namespace interop;
 
 class GIDebugRenderer : public IRenderer
 {
-    RenderGraph::ResourceHandle m_ProbePositionsRDGBufferHandle;
-    RenderGraph::ResourceHandle m_ProbeDrawIndirectArgsRDGBufferHandle;
-    RenderGraph::ResourceHandle m_InstanceIDToProbeIndexRDGBufferHandle;
+    // the pass's three transient outputs (GIRenderer.cpp:618-650), described once
+    struct Output
+    {
+        const char* debugName;
+        uint32_t stride;
+        bool perProbe;                 // one element per probe, else a single element
+        bool indirectArgs;
+        RenderGraph::ResourceHandle handle;
+        nvrhi::BufferHandle last;      // what the last frame wrote (trhost_gi_probe_buffers)
+    };
+    enum { kPositions, kDrawArgs, kInstanceToProbe, kNumOutputs };
+    Output m_Outputs[kNumOutputs] = {
+        { "Probe Positions", sizeof(float) * 3, true, false, {}, nullptr },
+        { "Probe Draw Indirect Args", sizeof(DrawIndexedIndirectArguments), false, true, {}, nullptr },
+        { "Instance ID to Probe Index", sizeof(uint32_t), true, false, {}, nullptr },
+    };
+
+    static GIProbeVisualizationUpdateConsts ConstantsOf(const Scene& scene)     // :687-708
+    {
+        const View& view = scene.m_View;
+        GIProbeVisualizationUpdateConsts k{};
+        k.m_NumProbes = scene.m_NumGIProbes;
+        k.m_Frustum = CullingFrustumOf(view.m_ViewToClip);
+        k.m_WorldToView = view.m_WorldToView;
+        k.m_HZBDimensions = Vector2U{ scene.m_HZB->getDesc().width, scene.m_HZB->getDesc().height };
+        k.m_P00 = view.m_ViewToClip.m[0][0];
+        k.m_P11 = view.m_ViewToClip.m[1][1];
+        k.m_NearPlane = view.m_ZNearP;
+        k.m_ProbeRadius = scene.m_GIProbeRadius;
+        k.m_bHideInactiveProbes = scene.m_bHideInactiveGIProbes;
+        return k;
+    }
 
 public:
-    nvrhi::BufferHandle m_LastProbePositions, m_LastProbeDrawIndirectArgs, m_LastInstanceIDToProbeIndex;
-
     GIDebugRenderer() : IRenderer("GIDebugRenderer") {}
+
+    nvrhi::BufferHandle LastOutput(int which) const { return m_Outputs[which].last; }
+    void DropLastOutputs() { for (Output& o : m_Outputs) o.last = nullptr; }
 
     bool Setup(RenderGraph& renderGraph) override
     {
-        if (!g_Scene->m_bShowGIProbes || g_Scene->m_NumGIProbes == 0) return false;   // :661-670: only with DDGI and the debug view on
         const uint32_t numProbes = g_Scene->m_NumGIProbes;
-        renderGraph.AddExternalReadDependency(g_Scene->m_HZB.Get());          // :652 AddReadDependency(volume descs) in the reference
-        {
-            nvrhi::BufferDesc desc;                                           // :618-626
-            desc.byteSize = sizeof(float) * 3ull * numProbes;
-            desc.structStride = sizeof(float) * 3;
+        if (numProbes == 0 || !g_Scene->m_bShowGIProbes) return false;          // :661-670: only with DDGI and the debug view on
+        renderGraph.AddExternalReadDependency(g_Scene->m_HZB.Get());            // where the reference declares the volume descriptors (:652)
+        for (Output& o : m_Outputs) {
+            nvrhi::BufferDesc desc;
+            desc.debugName = o.debugName;
+            desc.structStride = o.stride;
+            desc.byteSize = (uint64_t)o.stride * (o.perProbe ? numProbes : 1u);
             desc.canHaveUAVs = true;
-            desc.debugName = "Probe Positions";
-            desc.initialState = nvrhi::ResourceStates::ShaderResource;
-            renderGraph.CreateTransientResource(m_ProbePositionsRDGBufferHandle, desc);
-        }
-        {
-            nvrhi::BufferDesc desc;                                           // :628-639
-            desc.byteSize = sizeof(DrawIndexedIndirectArguments);
-            desc.structStride = sizeof(DrawIndexedIndirectArguments);
-            desc.canHaveUAVs = true;
-            desc.isDrawIndirectArgs = true;
-            desc.debugName = "Probe Draw Indirect Args";
-            desc.initialState = nvrhi::ResourceStates::IndirectArgument;
-            renderGraph.CreateTransientResource(m_ProbeDrawIndirectArgsRDGBufferHandle, desc);
-        }
-        {
-            nvrhi::BufferDesc desc;                                           // :641-650
-            desc.byteSize = sizeof(uint32_t) * (uint64_t)numProbes;
-            desc.structStride = sizeof(uint32_t);
-            desc.canHaveUAVs = true;
-            desc.debugName = "Instance ID to Probe Index";
-            desc.initialState = nvrhi::ResourceStates::ShaderResource;
-            renderGraph.CreateTransientResource(m_InstanceIDToProbeIndexRDGBufferHandle, desc);
+            desc.isDrawIndirectArgs = o.indirectArgs;
+            desc.initialState = o.indirectArgs ? nvrhi::ResourceStates::IndirectArgument : nvrhi::ResourceStates::ShaderResource;
+            renderGraph.CreateTransientResource(o.handle, desc);
         }
         return true;
     }
 
     void Render(nvrhi::CommandListHandle commandList, const RenderGraph& renderGraph) override
     {
-        nvrhi::BufferHandle probePositionsBuffer = renderGraph.GetBuffer(m_ProbePositionsRDGBufferHandle);              // :678-681
-        nvrhi::BufferHandle probeDrawIndirectArgsBuffer = renderGraph.GetBuffer(m_ProbeDrawIndirectArgsRDGBufferHandle);
-        nvrhi::BufferHandle instanceIDToProbeIndexBuffer = renderGraph.GetBuffer(m_InstanceIDToProbeIndexRDGBufferHandle);
+        nvrhi::BufferHandle out[kNumOutputs];
+        for (int i = 0; i < kNumOutputs; ++i) out[i] = renderGraph.GetBuffer(m_Outputs[i].handle);      // :678-681
 
-        DrawIndexedIndirectArguments indirectArgs{};                          // :683-685
-        indirectArgs.m_IndexCount = g_Scene->m_GIProbeSphereIndexCount;       // g_CommonResources.UnitSphere.m_NumIndices in the reference
-        commandList->writeBuffer(probeDrawIndirectArgsBuffer, &indirectArgs, sizeof(indirectArgs));
+        // the draw the culling feeds: unit-sphere indices, instance count 0 until the shader has counted (:683-685)
+        DrawIndexedIndirectArguments sphereDraw{};
+        sphereDraw.m_IndexCount = g_Scene->m_GIProbeSphereIndexCount;           // g_CommonResources.UnitSphere.m_NumIndices in the reference
+        commandList->writeBuffer(out[kDrawArgs], &sphereDraw, sizeof sphereDraw);
 
-        const uint32_t numProbes = g_Scene->m_NumGIProbes;                    // :687
-
-        Matrix projectionT = Transpose(g_Scene->m_View.m_ViewToClip);         // :691-695
-        Vector4 frustumX = Vector4{ projectionT.m[3][0] + projectionT.m[0][0], projectionT.m[3][1] + projectionT.m[0][1], projectionT.m[3][2] + projectionT.m[0][2], projectionT.m[3][3] + projectionT.m[0][3] };
-        Vector4 frustumY = Vector4{ projectionT.m[3][0] + projectionT.m[1][0], projectionT.m[3][1] + projectionT.m[1][1], projectionT.m[3][2] + projectionT.m[1][2], projectionT.m[3][3] + projectionT.m[1][3] };
-        frustumX = Normalize(frustumX);
-        frustumY = Normalize(frustumY);
-
-        GIProbeVisualizationUpdateConsts passParameters{};                    // :697-708
-        passParameters.m_NumProbes = numProbes;
-        passParameters.m_Frustum = Vector4{ frustumX.x, frustumX.z, frustumY.y, frustumY.z };
-        passParameters.m_WorldToView = g_Scene->m_View.m_WorldToView;
-        passParameters.m_HZBDimensions = Vector2U{ g_Scene->m_HZB->getDesc().width, g_Scene->m_HZB->getDesc().height };
-        passParameters.m_P00 = g_Scene->m_View.m_ViewToClip.m[0][0];
-        passParameters.m_P11 = g_Scene->m_View.m_ViewToClip.m[1][1];
-        passParameters.m_NearPlane = g_Scene->m_View.m_ZNearP;
-        passParameters.m_ProbeRadius = g_Scene->m_GIProbeRadius;
-        passParameters.m_bHideInactiveProbes = g_Scene->m_bHideInactiveGIProbes ? 1u : 0u;
-
-        nvrhi::BufferHandle passParametersBuffer = g_Graphic.CreateConstantBuffer(commandList, passParameters);   // :710
-
-        nvrhi::BindingSetDesc bindingSetDesc;                                 // :712-723 (t10 / u10: probe inputs instead of the DDGI volume)
-        bindingSetDesc.bindings = {
-            nvrhi::BindingSetItem::ConstantBuffer(0, passParametersBuffer),
-            nvrhi::BindingSetItem::Texture_SRV(0, g_Scene->m_HZB),
-            nvrhi::BindingSetItem::StructuredBuffer_SRV(10, g_Scene->m_GIProbePositionsBuffer),
-            nvrhi::BindingSetItem::StructuredBuffer_SRV(11, g_Scene->m_GIProbeStatesBuffer),
-            nvrhi::BindingSetItem::StructuredBuffer_UAV(0, probePositionsBuffer),
-            nvrhi::BindingSetItem::StructuredBuffer_UAV(1, probeDrawIndirectArgsBuffer),
-            nvrhi::BindingSetItem::StructuredBuffer_UAV(2, instanceIDToProbeIndexBuffer),
-            nvrhi::BindingSetItem::Sampler(0, g_CommonResources.LinearClampMinReductionSampler),
+        const GIProbeVisualizationUpdateConsts consts = ConstantsOf(*g_Scene);
+        using Item = nvrhi::BindingSetItem;
+        Graphic::ComputePassParams pass;                                        // :710-733
+        pass.m_CommandList = commandList;
+        pass.m_ShaderName = "giprobevisualization_CS_VisualizeGIProbesCulling";
+        pass.m_DispatchGroupSize = ComputeShaderUtils::GetGroupCount(consts.m_NumProbes, kNumThreadsPerWave);
+        pass.m_BindingSetDesc.bindings = {
+            Item::ConstantBuffer(0, g_Graphic.CreateConstantBuffer(commandList, consts)),
+            Item::Texture_SRV(0, g_Scene->m_HZB),
+            Item::Sampler(0, g_CommonResources.LinearClampMinReductionSampler),
+            // t10 / t11: probe positions and states, where the reference binds the DDGI volume descriptors (t10) and
+            // the probe-data texture array (u10)
+            Item::StructuredBuffer_SRV(10, g_Scene->m_GIProbePositionsBuffer),
+            Item::StructuredBuffer_SRV(11, g_Scene->m_GIProbeStatesBuffer),
+            Item::StructuredBuffer_UAV(0, out[kPositions]),
+            Item::StructuredBuffer_UAV(1, out[kDrawArgs]),
+            Item::StructuredBuffer_UAV(2, out[kInstanceToProbe]),
         };
+        g_Graphic.AddComputePass(pass);
 
-        Graphic::ComputePassParams computePassParams;                         // :725-731
-        computePassParams.m_CommandList = commandList;
-        computePassParams.m_ShaderName = "giprobevisualization_CS_VisualizeGIProbesCulling";
-        computePassParams.m_BindingSetDesc = bindingSetDesc;
-        computePassParams.m_DispatchGroupSize = ComputeShaderUtils::GetGroupCount(numProbes, kNumThreadsPerWave);
-        g_Graphic.AddComputePass(computePassParams);
-
-        m_LastProbePositions = probePositionsBuffer;
-        m_LastProbeDrawIndirectArgs = probeDrawIndirectArgsBuffer;
-        m_LastInstanceIDToProbeIndex = instanceIDToProbeIndexBuffer;
+        for (int i = 0; i < kNumOutputs; ++i) m_Outputs[i].last = out[i];
     }
+
+    enum { Positions = kPositions, DrawArgs = kDrawArgs, InstanceToProbe = kInstanceToProbe };
 };
 DEFINE_RENDERER(GIDebugRenderer);
 
 bool GetGIProbeCullBuffers(nvrhi::BufferHandle* positions, nvrhi::BufferHandle* drawArgs, nvrhi::BufferHandle* instanceToProbe)
 {
-    GIDebugRenderer* r = static_cast<GIDebugRenderer*>(g_GIDebugRenderer);
-    if (!r->m_LastProbeDrawIndirectArgs) return false;
-    *positions = r->m_LastProbePositions; *drawArgs = r->m_LastProbeDrawIndirectArgs; *instanceToProbe = r->m_LastInstanceIDToProbeIndex;
+    const GIDebugRenderer* r = static_cast<const GIDebugRenderer*>(g_GIDebugRenderer);
+    if (!r->LastOutput(GIDebugRenderer::DrawArgs)) return false;
+    *positions = r->LastOutput(GIDebugRenderer::Positions);
+    *drawArgs = r->LastOutput(GIDebugRenderer::DrawArgs);
+    *instanceToProbe = r->LastOutput(GIDebugRenderer::InstanceToProbe);
     return true;
 }
 
-void ReleaseGIProbeCullBuffers()
-{
-    GIDebugRenderer* r = static_cast<GIDebugRenderer*>(g_GIDebugRenderer);
-    r->m_LastProbePositions = nullptr; r->m_LastProbeDrawIndirectArgs = nullptr; r->m_LastInstanceIDToProbeIndex = nullptr;
-}
+void ReleaseGIProbeCullBuffers() { static_cast<GIDebugRenderer*>(g_GIDebugRenderer)->DropLastOutputs(); }

@@ -56,6 +56,17 @@ inline Vector4 Normalize(const Vector4& v)
     return Vector4{ v.x / l, v.y / l, v.z / l, v.w / l };
 }
 
+// The four numbers FrustumCull reads (culling.hlsli:11-12): x and z of the normalised left/right plane, y and z of the
+// normalised top/bottom plane, from the projection's columns 0, 1 and 3 (BasePassRenderers.cpp:557-563 and
+// GIRenderer.cpp:691-695 spell this out with a transposed matrix; same arithmetic, same order).
+inline Vector4 CullingFrustumOf(const Matrix& viewToClip)
+{
+    const float (*p)[4] = viewToClip.m;
+    const Vector4 sideways = Normalize(Vector4{ p[0][3] + p[0][0], p[1][3] + p[1][0], p[2][3] + p[2][0], p[3][3] + p[3][0] });
+    const Vector4 upright = Normalize(Vector4{ p[0][3] + p[0][1], p[1][3] + p[1][1], p[2][3] + p[2][1], p[3][3] + p[3][1] });
+    return Vector4{ sideways.x, sideways.z, upright.y, upright.z };
+}
+
 // MathUtilities.cpp:3-38
 void ModifyPerspectiveMatrix(Matrix& mat, float nearPlane, float farPlane, bool bReverseZ, bool bInfiniteZ);
 // XMMatrixPerspectiveFovRH (SimpleMath.inl:2193-2199)
