@@ -234,6 +234,8 @@ __device__ __forceinline__ uint32_t classify(const InstanceCullArgs& a, uint32_t
 // C3 (early 781 k entries, late ~100 k): 1024 x 2 entries per workgroup: early 49 + 6 + 24 us, late 14 + 7 + 26 us (too few
 // workgroups for the late list); 512 x 1: 37 + 13 + 23 / 7 + 5 + 6 us (shipped); 256 x 1: 36 + 21 + 25 / 7 + 5 + 8 us (the
 // histogram matrix the scan walks grows with the number of workgroups).  Round-1 scheme with global atomics: 47 + 11 + 30 / 6 + 10 + 12.
+// End of round 2 (16 x 16 tiles, LOD tables as planes, cooperative entry stores, rows requested before the list length):
+// early 23 + 8 + 16 us; the late pass runs the single-launch kernel below whatever its capacity (8 us).
 #ifndef TR_BIG_THREADS
 #define TR_BIG_THREADS 512
 #endif
