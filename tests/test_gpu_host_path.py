@@ -86,11 +86,16 @@ def test_group_cap_q2_through_host(oracle):
         assert ref.dispatchArgs[0][0] > 257 > ref.validRecords[0]
 
 
-@pytest.mark.parametrize("async_compute", [False, True])
-def test_animated_transforms_then_cull(oracle, async_compute):
+@pytest.mark.parametrize("async_compute,rebuild_cache", [(False, False), (False, True), (True, False)])
+def test_animated_transforms_then_cull(oracle, monkeypatch, async_compute, rebuild_cache):
     """configs[4] in miniature: UpdateInstanceConstsRenderer rewrites the world matrices on the GPU every
     frame from the node hierarchy, then the cull runs on them.  async_compute: the update pass records for the compute
-    queue; the base pass (graphics queue) reads the instance buffer it writes, so the graph makes it wait."""
+    queue; the base pass (graphics queue) reads the instance buffer it writes, so the graph makes it wait.
+    From the second frame on the update kernel also refreshes the transform-dependent entries of the instance cull cache
+    in place (k_updateinstance.hip); rebuild_cache switches that off (the next cull pass then rebuilds the whole cache):
+    both ways the frames equal the oracle's."""
+    if rebuild_cache:
+        monkeypatch.setenv("TRHIP_NO_CACHE_REFRESH", "1")
     rng = np.random.default_rng(3)
     view = synth.make_view(render=(640, 360))
     spec = synth.SceneSpec(num_meshes=12, num_instances=200, meshlets_lod0=40, jitter_meshlets=True, max_lods=3, seed=9)

@@ -20,13 +20,15 @@ struct InstanceCullCache
                                     // of the selected LOD are a coalesced read over consecutive ids (as [id][lod] a lane pulled
                                     // a 64-byte granule for them: 2/3 of the bytes classify moved on C3)
     const float* error;             // [lod][id]
+    const float4* localSphere;      // [id] the mesh's bounding sphere in mesh space: lets the transform update refresh the
+                                    // transform-dependent entries (world, sphere, maxScale) without the mesh table
     uint64_t stride;                // ids per plane
 
     __host__ __device__ const uint2& lod(uint32_t id, uint32_t l) const { return lodInfo[(uint64_t)l * stride + id]; }
     __host__ __device__ const float& err(uint32_t id, uint32_t l) const { return error[(uint64_t)l * stride + id]; }
 };
 
-constexpr uint64_t kInstanceCacheBytesPerInstance = 64 + 16 + 4 + 4 + 3 * 4 * interop::kMaxNumMeshLODs;
+constexpr uint64_t kInstanceCacheBytesPerInstance = 64 + 16 + 4 + 4 + 3 * 4 * interop::kMaxNumMeshLODs + 16;
 
 inline InstanceCullCache instanceCacheLayout(void* base, uint64_t n)
 {
@@ -37,7 +39,26 @@ inline InstanceCullCache instanceCacheLayout(void* base, uint64_t n)
     c.maxScale = (const float*)p;           p += 4 * n;
     c.numLODs = (const uint32_t*)p;         p += 4 * n;
     c.lodInfo = (const uint2*)p;            p += 8ull * interop::kMaxNumMeshLODs * n;
-    c.error = (const float*)p;
+    c.error = (const float*)p;              p += 4ull * interop::kMaxNumMeshLODs * n;
+    c.localSphere = (const float4*)p;
     c.stride = n;
     return c;
+}
+
+// The entries of instance i that depend on its world matrix (rows w0..w3 as stored in BasePassInstanceConstants), from
+// the mesh-space bounding sphere: what instanceCacheKernel writes, and what the transform update re-writes in place
+// (k_updateinstance.hip) so that an animated frame does not re-read 300 B per instance to rebuild the whole cache.
+// Needs cull_math.hip.h before this header.
+__device__ __forceinline__ void instanceCacheWriteTransformPart(const InstanceCullCache& c, uint32_t i, float4 w0, float4 w1, float4 w2, float4 w3, float4 sph)
+{
+    const cm::M43 W = { { w0.x, w0.y, w0.z }, { w1.x, w1.y, w1.z }, { w2.x, w2.y, w2.z }, { w3.x, w3.y, w3.z } };
+    const float ms = cm::maxScale(W.r0, W.r1, W.r2);                                 // toyrenderer_common.hlsli:134-140
+    const cm::F3 wc = cm::mulPoint({ sph.x, sph.y, sph.z }, W);                      // gpuculling.hlsl:116 TransformBoundingSphereToWorld
+    const_cast<float4*>(c.sphere)[i] = make_float4(wc.x, wc.y, wc.z, sph.w * ms);
+    float4* wr = const_cast<float4*>(c.world) + 4ull * i;
+    wr[0] = make_float4(w0.x, w0.y, w0.z, w1.x);
+    wr[1] = make_float4(w1.y, w1.z, w2.x, w2.y);
+    wr[2] = make_float4(w2.z, w3.x, w3.y, w3.z);
+    wr[3] = make_float4(ms, 0.f, 0.f, 0.f);
+    const_cast<float*>(c.maxScale)[i] = ms;
 }

@@ -83,7 +83,6 @@ __global__ __launch_bounds__(256) void instanceCacheKernel(const BasePassInstanc
     const float4 w1 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[1]);
     const float4 w2 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[2]);
     const float4 w3 = *reinterpret_cast<const float4*>(inst.m_WorldMatrix.m[3]);
-    const cm::M43 W = { { w0.x, w0.y, w0.z }, { w1.x, w1.y, w1.z }, { w2.x, w2.y, w2.z }, { w3.x, w3.y, w3.z } };
     const uint32_t meshIdx = inst.m_MeshDataIdx;
     float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t numLODs = 0;
@@ -100,15 +99,8 @@ __global__ __launch_bounds__(256) void instanceCacheKernel(const BasePassInstanc
             nm[l] = mesh.m_MeshLODDatas[l].m_NumMeshlets; mb[l] = mesh.m_MeshLODDatas[l].m_MeshletDataBufferIdx; err[l] = mesh.m_MeshLODDatas[l].m_Error;
         }
     }
-    const float ms = cm::maxScale(W.r0, W.r1, W.r2);
-    const cm::F3 wc = cm::mulPoint({ sph.x, sph.y, sph.z }, W);                      // :116 TransformBoundingSphereToWorld
-    const_cast<float4*>(c.sphere)[i] = make_float4(wc.x, wc.y, wc.z, sph.w * ms);
-    float4* wr = const_cast<float4*>(c.world) + 4ull * i;
-    wr[0] = make_float4(w0.x, w0.y, w0.z, w1.x);
-    wr[1] = make_float4(w1.y, w1.z, w2.x, w2.y);
-    wr[2] = make_float4(w2.z, w3.x, w3.y, w3.z);
-    wr[3] = make_float4(ms, 0.f, 0.f, 0.f);
-    const_cast<float*>(c.maxScale)[i] = ms;
+    instanceCacheWriteTransformPart(c, i, w0, w1, w2, w3, sph);
+    const_cast<float4*>(c.localSphere)[i] = sph;
     const_cast<uint32_t*>(c.numLODs)[i] = numLODs;
 #pragma unroll
     for (uint32_t l = 0; l < kMaxNumMeshLODs; ++l) {

@@ -5,8 +5,11 @@
 // TRS -> matrix, multiply up the parent chain, Prev = World, World = new.  The TLAS instance
 // descriptor write (:38-52) is ray tracing and out of scope; u1 is accepted and ignored.
 //
-// HBM traffic per instance: 4 B node id + 48 B per hierarchy level + 64 B read + 128 B written.
+// HBM traffic per instance: 4 B node id + 48 B per hierarchy level + 64 B read + 128 B written; + 16 B read and 84 B
+// written when the kernel also refreshes the transform-dependent entries of the instance cull cache (instance_cache.hip.h)
+// -- otherwise the next cull pass rebuilds the whole cache: 300 B read + 200 B written per instance, every animated frame.
 #include "cull_math.hip.h"
+#include "instance_cache.hip.h"
 #include "trhip_internal.h"
 
 using namespace interop;
@@ -52,7 +55,8 @@ __device__ __forceinline__ M44 makeWorldMatrix(const NodeLocalTransform& t)
 
 __global__ __launch_bounds__(256) void updateInstanceConstsKernel(const NodeLocalTransform* __restrict__ nodes, uint32_t numNodes,
                                                                   const uint32_t* __restrict__ primToNode,
-                                                                  BasePassInstanceConstants* instances, uint32_t n)
+                                                                  BasePassInstanceConstants* instances, uint32_t n,
+                                                                  bool refreshCache, InstanceCullCache cache)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;                                                           // :13-16
@@ -69,11 +73,15 @@ __global__ __launch_bounds__(256) void updateInstanceConstsKernel(const NodeLoca
     }
     float4* w = reinterpret_cast<float4*>(&instances[i].m_WorldMatrix);
     float4* p = reinterpret_cast<float4*>(&instances[i].m_PrevWorldMatrix);
+    float4 rows[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+        rows[r] = make_float4(world.m[r][0], world.m[r][1], world.m[r][2], world.m[r][3]);
         p[r] = w[r];                                                              // :35
-        w[r] = make_float4(world.m[r][0], world.m[r][1], world.m[r][2], world.m[r][3]); // :36
+        w[r] = rows[r];                                                           // :36
     }
+    // the cull cache's view of this instance, from the same four rows the cache builder would read back
+    if (refreshCache) instanceCacheWriteTransformPart(cache, i, rows[0], rows[1], rows[2], rows[3], cache.localSphere[i]);
 }
 
 int recordUpdateInstanceConsts(trhip::DispatchCtx& ctx)
@@ -97,7 +105,17 @@ int recordUpdateInstanceConsts(trhip::DispatchCtx& ctx)
     const uint32_t* pn = (const uint32_t*)primToNode->ptr;
     BasePassInstanceConstants* ip = (BasePassInstanceConstants*)instances->ptr;
     ctx.emit("main", [=](hipStream_t s) {
-        hipLaunchKernelGGL(updateInstanceConstsKernel, dim3((n + 255) / 256), dim3(256), 0, s, np, numNodes, pn, ip, n);
+        // At submission time: this command's write has already been counted in the buffer's version.  If the cull cache
+        // was current for the contents this command replaces, the kernel keeps it current (the entries that depend on
+        // the world matrix are re-written from the new one; LOD tables and mesh-space spheres do not change), and the
+        // next cull pass finds nothing to rebuild.  A changed mesh buffer is still caught there (its own version).
+        const uint64_t now = instances->version;
+        const bool refresh = instances->cullCache && instances->cullCacheMesh && instances->cullCacheInstVersion + 1 == now &&
+                             instances->cullCacheBytes >= (instances->byteSize / sizeof(BasePassInstanceConstants)) * kInstanceCacheBytesPerInstance &&
+                             !getenv("TRHIP_NO_CACHE_REFRESH");
+        const InstanceCullCache cache = refresh ? instanceCacheLayout(instances->cullCache, instances->byteSize / sizeof(BasePassInstanceConstants)) : InstanceCullCache{};
+        hipLaunchKernelGGL(updateInstanceConstsKernel, dim3((n + 255) / 256), dim3(256), 0, s, np, numNodes, pn, ip, n, refresh, cache);
+        if (refresh) instances->cullCacheInstVersion = now;
         return trhip::launchStatus("updateInstanceConstsKernel"); });
     return TRHIP_OK;
 }
