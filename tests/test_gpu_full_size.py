@@ -83,6 +83,23 @@ def test_c2_instanced_50m_meshlets_two_phase(oracle):
         _properties(got, s)
 
 
+def test_large_pass_with_long_ragged_runs(oracle):
+    """The three-kernel instance pass (more than 2^17 list entries) on meshes of 150-350 meshlets and up to 4 LODs: 1 to 11
+    groups per submitted instance, ragged last groups -- the emit kernel's four-lane entry stores only cover a run's first
+    four groups (longer runs finish lane by lane), its 16-byte record stores come in fours with a lane-by-lane remainder,
+    and the late pass takes the single-launch kernel at a capacity far above its usual 2^17 entries."""
+    spec = synth.SceneSpec(num_meshes=300, num_instances=180_000, meshlets_lod0=280, jitter_meshlets=True, max_lods=4, alpha_mask_fraction=0.1, seed=21)
+    cap = spec.num_instances * ((spec.meshlets_lod0 * 2 + 31) // 32) + 1
+    got, ref = _run(oracle, spec, frames=2, cap=cap)
+    assert all(ref.passRan)
+    offsets = np.ascontiguousarray(ref.records[0]).view(np.uint32).reshape(-1, 3)[:, 2]          # m_MeshletGroupOffset
+    groups_per_run = np.diff(np.flatnonzero(np.concatenate([offsets == 0, [True]])))
+    assert groups_per_run.max() >= 9 and groups_per_run.min() <= 2 and len(np.unique(groups_per_run)) >= 8
+    assert int(ref.lateCount[0]) > 64
+    for s in range(4):
+        _properties(got, s)
+
+
 def test_c3_bench_workload_100m_meshlets(oracle):
     spec = synth.config_spec("C3")
     cap = spec.num_instances * ((spec.meshlets_lod0 + 31) // 32) + 1
