@@ -204,12 +204,13 @@ def test_overflow_is_flagged_not_silent(dev):
     assert _unpack(dev, sl, 1, S, (0,), S, 32 * S, slot_runs=12)[0]["status"] & (gather.STATUS_SLOT_OVERFLOW | gather.STATUS_BAD_HEADER)
 
 
-@pytest.mark.parametrize("world", [2, 5])
-def test_sharded_frames_gather_to_the_single_gpu_result(dev, oracle, world):
+@pytest.mark.parametrize("world,instances,meshlets", [(2, 3001, 70), (5, 3001, 70), (3, 1500, 260)])
+def test_sharded_frames_gather_to_the_single_gpu_result(dev, oracle, world, instances, meshlets):
     """Cull `world` contiguous instance shards (FrameDriver, one after the other on this GPU), pack, lay the
     slots out rank-major, unpack: records and visible lists of both phases == the oracle's full-scene frame."""
     from toyrenderer_amd.frame import FrameDriver, GpuScene
-    spec = synth.SceneSpec(num_meshes=40, num_instances=3001, meshlets_lod0=70, jitter_meshlets=True, max_lods=4, seed=7)
+    # (the third case: runs of up to 11 groups per instance through the run encoding)
+    spec = synth.SceneSpec(num_meshes=40, num_instances=instances, meshlets_lod0=meshlets, jitter_meshlets=True, max_lods=4, seed=7)
     scene = synth.make_scene(spec)
     view = synth.make_view(eye=(0.3, 0.1, 0.4), yaw=0.02, prev_eye=(0, 0, 0), prev_yaw=0.0, render=(1280, 720))
     d_prev = synth.gen_depth(view, 60, seed=5, scale=3.0)
