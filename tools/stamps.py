@@ -22,9 +22,10 @@ for _ in range(3):
 r.wait_idle()
 L.trhip_debug_read_stamps(out, 1)
 v = np.array(list(out), float)
-names = ["between batches", "prologue", "wait data+xchg+transform+frustum", "occl prepare+texel issue", "prefetch issue+cone", "texel wait+resolve", "ballot+store", "loop overhead"]
+names = ["0 between batches (drain, fixups, mask store)", "1 prologue (entry -> instance block -> LDS)", "2 wait for the slot + transform + frustum", "3 quotients + cone", "4 lookup + prefetch issue", "5 lookup wait + resolve", "6 ballot + mask to LDS", "7 loop overhead"]
 tot = v.sum()
+WAVES = 256 * 4 * int(os.environ.get("TRHIP_AS_BLOCKS_PER_CU", "4"))
 for n, x in zip(names, v):
-    print(f"{n:40s} {x/tot*100:6.2f} %   {x/3/6144:12.0f} cycles per wave per frame")
-print("total cycles per wave per frame", tot / 3 / 6144)
+    print(f"{n:48s} {x/tot*100:6.2f} %   {x/3/WAVES:12.0f} cycles per wave per frame (both cull launches)")
+print("total cycles per wave per frame", tot / 3 / WAVES)
 r.shutdown()

@@ -19,9 +19,10 @@ constexpr int kIters = 512;
 
 #define REP16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 
-enum Kind { FMA = 0, PKFMA, RCP, RSQ, MUL, PKMUL, FMAC, CNDMASK, MIX_PK_SCALAR, SQRT, CMP, ADD_U32, BCNT, KINDS };
+enum Kind { FMA = 0, PKFMA, RCP, RSQ, MUL, PKMUL, FMAC, CNDMASK, MIX_PK_SCALAR, SQRT, CMP, ADD_U32, BCNT, DEP_FMA, DEP_PKFMA, CMP_SGPR, KINDS };
 static const char* kNames[KINDS] = { "v_fma_f32", "v_pk_fma_f32", "v_rcp_f32", "v_rsq_f32", "v_mul_f32", "v_pk_mul_f32", "v_fmac_f32 (VOP2)",
-                                     "v_cndmask_b32", "v_pk_fma_f32 + v_fma_f32 alternating", "v_sqrt_f32", "v_cmp_lt_f32 (-> vcc)", "v_add_u32", "v_bcnt_u32_b32" };
+                                     "v_cndmask_b32 (reads vcc)", "v_pk_fma_f32 + v_fma_f32 alternating", "v_sqrt_f32", "v_cmp_lt_f32 (-> vcc)", "v_add_u32", "v_bcnt_u32_b32",
+                                     "v_fma_f32, ONE dependent chain", "v_pk_fma_f32, ONE dependent chain", "v_cmp_lt_f32_e64 (-> sgpr pair)" };
 
 template <int K>
 __global__ __launch_bounds__(1024) void rateKernel(unsigned long long* stamps, float seed, float* sink)
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(1024) void rateKernel(unsigned long long* stamps, f
             REP16(M)
 #undef M
         } else if (K == CNDMASK) {
-#define M(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(a) : "vcc");
+#define M(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(a));
             REP16(M)
 #undef M
         } else if (K == MIX_PK_SCALAR) {
@@ -84,6 +85,18 @@ __global__ __launch_bounds__(1024) void rateKernel(unsigned long long* stamps, f
 #undef M
         } else if (K == ADD_U32) {
 #define M(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[i]) : "v"(u));
+            REP16(M)
+#undef M
+        } else if (K == DEP_FMA) {
+#define M(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[0]) : "v"(a), "v"(b));
+            REP16(M)
+#undef M
+        } else if (K == DEP_PKFMA) {
+#define M(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[0]) : "v"(a2), "v"(b2));
+            REP16(M)
+#undef M
+        } else if (K == CMP_SGPR) {
+#define M(i) asm volatile("v_cmp_lt_f32_e64 s[20:21], %0, %1" :: "v"(r[i]), "v"(a) : "s20", "s21");
             REP16(M)
 #undef M
         } else if (K == BCNT) {
@@ -107,7 +120,7 @@ __global__ __launch_bounds__(1024) void rateKernel(unsigned long long* stamps, f
 template <int K>
 static void run(int wavesPerSimd, unsigned long long* dStamps, float* sink, int numCUs)
 {
-    const int threads = 256 * std::min(wavesPerSimd, 4);
+    const int threads = 256 * std::min(wavesPerSimd, 4);   // 1024 threads = the most a workgroup holds: 4 waves per SIMD
     const int blocksPerCU = wavesPerSimd <= 4 ? 1 : wavesPerSimd / 4;
     const int grid = numCUs * blocksPerCU;
     const int wavesPerBlock = threads / 64;
@@ -140,7 +153,7 @@ int main()
     printf("%s, %d CUs, clock %d MHz\n", prop.name, numCUs, prop.clockRate / 1000);
     unsigned long long* dStamps; float* sink;
     CK(hipMalloc(&dStamps, 2ull * 8 * numCUs * 2 * 16)); CK(hipMalloc(&sink, 4));
-    for (int w : { 1, 2, 4, 8 }) {
+    for (int w : { 1, 2, 3, 4 }) {
         run<FMA>(w, dStamps, sink, numCUs);
         run<FMAC>(w, dStamps, sink, numCUs);
         run<MUL>(w, dStamps, sink, numCUs);
@@ -154,6 +167,9 @@ int main()
         run<CMP>(w, dStamps, sink, numCUs);
         run<ADD_U32>(w, dStamps, sink, numCUs);
         run<BCNT>(w, dStamps, sink, numCUs);
+        run<CMP_SGPR>(w, dStamps, sink, numCUs);
+        run<DEP_FMA>(w, dStamps, sink, numCUs);
+        run<DEP_PKFMA>(w, dStamps, sink, numCUs);
         printf("\n");
     }
     return 0;

@@ -60,12 +60,19 @@ constexpr uint32_t kWaves = kBlock / 64;
 constexpr uint32_t kBatch = 64;                  // records per wave batch
 constexpr uint32_t kSteps = kBatch / 2;          // two records per wave step
 #ifndef TR_RING_SLOTS
-#define TR_RING_SLOTS 3      /* steps of MeshletData in flight per wave (2 KB each, staged in LDS) */
+#define TR_RING_SLOTS 2      /* steps of MeshletData in flight per wave (2 KB each, staged in LDS) */
 #endif
 #ifndef TR_CULL_BATCH
 /* records per wave and prologue: a multiple of 2 * TR_RING_SLOTS.  Measured on C3 with 2 ring slots: 64 records (47 KB of
  * LDS per workgroup, 3 workgroups per CU) 0.511 ms, 32 (34 KB, 4 per CU) 0.482 ms, 16 (5 per CU) 0.498 ms. */
 #define TR_CULL_BATCH (TR_RING_SLOTS == 3 ? 30 : 32)
+#endif
+#ifndef TR_DEFER
+/* 1: the occlusion lookup of step s is consumed at the END OF STEP s + 1 (its value rides through a whole step of
+ * arithmetic in a register).  Loads return in order, so a wait for the lookup of step s also waits for every ring slot
+ * requested before it: consumed in its own step (0, rounds 1-2) the wait pinned the ring to ONE step of lead whatever its
+ * depth -- 26 % of the wave-cycles sat in that wait even with the lookups compiled out (profiles/r3/experiments.md). */
+#define TR_DEFER 1
 #endif
 constexpr uint32_t kCullBatch = TR_CULL_BATCH;   // meshlet cull: records a wave resolves per prologue (<= 64: one per lane)
 constexpr uint32_t kCullSteps = kCullBatch / 2;
@@ -157,6 +164,9 @@ __device__ __forceinline__ void issueMeshletLoads(char* slotLds /* wave-uniform 
     // depends on the data.
     const uint32_t nChunks = count * 2u;
     const uint32_t ja = sub < nChunks ? sub : 0u, jb = 32u + sub < nChunks ? 32u + sub : 0u;
+#ifdef TR_EXP_NOMEM      /* experiment, results WRONG: every wave streams the same 2 KB (cache hits): the kernel without its HBM traffic */
+    firstIdx &= 63u;
+#endif
     const char* p = reinterpret_cast<const char*>(meshlets + firstIdx);
     const char* pa = p + 16u * ja;                                                   // basepass.hlsl:65
     const char* pb = p + 16u * jb;
@@ -197,8 +207,11 @@ __device__ __forceinline__ void issueMeshletLoads(char* slotLds /* wave-uniform 
 // TABLE: resolve the HZB lookup through the footprint-min table (one 2-byte load; the early pass, where the
 // table is rebuilt once per frame behind the instance pass) or through the texels themselves (two texel-pair
 // loads; the late pass, which is small and follows an HZB rebuild).  Same results either way.
+#ifndef TR_CULL_WAVES_PER_EU
+#define TR_CULL_WAVES_PER_EU 5   /* waves per SIMD the register allocation aims at (<= 96 VGPRs); LDS: 5 workgroups of 31.3 KB per CU */
+#endif
 template <bool FRUSTUM, bool OCCLUSION, bool CONE, bool TABLE>
-__global__ __launch_bounds__(kCullBlock) void meshletCullKernel(MeshletCullArgs a)
+__global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullKernel(MeshletCullArgs a)
 {
 #ifdef TR_STAMPS
     unsigned long long stampSum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -211,7 +224,7 @@ __global__ __launch_bounds__(kCullBlock) void meshletCullKernel(MeshletCullArgs 
     __shared__ uint4 s_mipTab[17];                     // table path: per-mip constants indexed by exponent + 1 (cm::occTailQuad)
     __shared__ uint32_t s_slowAll[kCullWaves][kSlowCap];
     __shared__ uint32_t s_slowCount[kCullWaves];
-    __shared__ uint32_t s_maskAll[kCullWaves][kCullBatch];
+    __shared__ uint32_t s_maskAll[kCullWaves][kCullBatch + 2];   // [0], [1]: where the deferred resolve of "the step before the first" lands
     __shared__ __attribute__((aligned(16))) char s_ring[kCullWaves][kRingSlots][2048];   // per wave: the ring slots of staged MeshletData
 
     const uint32_t G = groupCount(a);
@@ -335,15 +348,54 @@ __global__ __launch_bounds__(kCullBlock) void meshletCullKernel(MeshletCullArgs 
         // at the top, vmcnt(2) for the lookup.
         char* const ring = s_ring[__builtin_amdgcn_readfirstlane((int)wave)][0];
         const uint32_t ringOff = (sub < 16u ? 0u : 512u) + half * 512u + sub * 32u;  // this lane's meshlet inside a ring slot
+        // The occlusion lookup of a step (TABLE: one 2-byte table entry; texel path: two texel pairs), issued for the lanes
+        // still in the race -- and ALWAYS for lane 0 (any in-range address), so that the instruction issues whatever the
+        // data: the hand-counted waits below rely on a fixed number of loads per step.
+        constexpr uint32_t kLk = !OCCLUSION ? 0u : TABLE ? 1u : 2u;                  // lookup loads per step
+        constexpr bool kDefer = TR_DEFER && OCCLUSION;
+        // In flight across a step boundary (kDefer): the raw lookup words of step s live in lk0 / lk1[s % slots] until the
+        // end of step s + 1; the rest of that step's decision rides along in ordinary registers.
+        uint32_t lk0[kRingSlots], lk1[kRingSlots];
 #pragma unroll
-        for (uint32_t k = 0; k < kRingSlots; ++k)
-            issueMeshletLoads(ring + 2048u * k, a.meshlets, s_rec[2 * k + half].first, s_rec[2 * k + half].count, sub);
-
-        auto step = [&](char* slot, uint32_t s) {
+        for (uint32_t k = 0; k < kRingSlots; ++k) { lk0[k] = 0u; lk1[k] = 0u; }
+        bool pVis = false, pAccept = false, pPair = false;
+        float pDepth = 0.f;
+        auto issueLookup = [&](uint32_t& w0, uint32_t& w1, const void* p0, const void* p1, bool want) {
+            const unsigned long long m = __ballot(want) | 1ull;
+            unsigned long long sv;
+            if (TABLE)
+                asm volatile("s_mov_b64 %[sv], exec\n\ts_and_b64 exec, exec, %[m]\n\tglobal_load_ushort %[d], %[a], off\n\ts_mov_b64 exec, %[sv]"
+                             : [d] "+v"(w0), [sv] "=&s"(sv) : [a] "v"(p0), [m] "s"(m) : "memory", "scc");
+            else
+                asm volatile("s_mov_b64 %[sv], exec\n\ts_and_b64 exec, exec, %[m]\n\tglobal_load_dword %[d0], %[a0], off\n\tglobal_load_dword %[d1], %[a1], off\n\ts_mov_b64 exec, %[sv]"
+                             : [d0] "+v"(w0), [d1] "+v"(w1), [sv] "=&s"(sv) : [a0] "v"(p0), [a1] "v"(p1), [m] "s"(m) : "memory", "scc");
+        };
+        // the mask of batch record r lives at s_mask[r + 2]
+        auto resolve = [&](uint32_t r2, bool vis, bool accept, bool pair, float depthSphere, uint32_t w0, uint32_t w1) {
+            bool visO;
+            if (TABLE) {
+                const float footprintMin = (float)__builtin_bit_cast(_Float16, (uint16_t)w0);
+                visO = accept | (depthSphere >= footprintMin);                                     // :81
+            } else {
+                cm::OccSample os; os.accept = accept; os.pair = pair; os.depthSphere = depthSphere; os.i0 = os.i1 = 0;
+                visO = cm::occlusionResolve(os, w0, w1);
+            }
+            vis &= visO;
+            // :116,120 WavePrefix/ActiveCountBits: lanes 0-31 ran record 2s, lanes 32-63 record 2s+1, in meshlet order
+            const unsigned long long ballot = __ballot(vis);
+            const uint32_t mask = half ? (uint32_t)(ballot >> 32) : (uint32_t)ballot;
+            if (sub == 0) s_mask[r2] = mask;            // LDS: the loop issues no stores to memory
+        };
+        auto step = [&](auto kc, uint32_t s) {
+            constexpr uint32_t kSlot = decltype(kc)::value, kPrev = (kSlot + kRingSlots - 1u) % kRingSlots;
+            char* const slot = ring + 2048u * kSlot;
             TR_STAMP(7);   // loop overhead / previous tail
             const uint32_t r = 2 * s + half;                                         // record within the batch
             const RecordInfo& ri = s_rec[r];
-            if (kRingSlots == 3) TR_WAIT_VMCNT(4); else TR_WAIT_VMCNT(2);            // this slot has landed
+            // Loads outstanding at the top of a step, oldest first: this step's slot (2), then per other slot its 2 -- with the
+            // previous step's lookup (kLk loads, kDefer) in front of the youngest slot's.
+            if (kDefer) { if (kRingSlots == 3) { if (kLk == 1) TR_WAIT_VMCNT(5); else TR_WAIT_VMCNT(6); } else { if (kLk == 1) TR_WAIT_VMCNT(3); else TR_WAIT_VMCNT(4); } }
+            else { if (kRingSlots == 3) TR_WAIT_VMCNT(4); else TR_WAIT_VMCNT(2); }   // this slot has landed
             const v4f sph = *reinterpret_cast<const v4f*>(slot + ringOff);
             const uint32_t cone = *reinterpret_cast<const uint32_t*>(slot + ringOff + 16u);
             const float4 sphere = make_float4(sph.x, sph.y, sph.z, sph.w);
@@ -360,46 +412,24 @@ __global__ __launch_bounds__(kCullBlock) void meshletCullKernel(MeshletCullArgs 
             cm::StepQuot q;
             if (OCCLUSION || CONE)
                 cm::stepQuotients<OCCLUSION, CONE>(active, cv, rad, cone, adjugateOf(ri), a.k.m_NearPlane, nearInRange, q);
-            cm::OccQuad oq;
-            cm::OccSample os;
-            uint32_t footprintBits = 0, row0 = 0, row1 = 0;
             if (CONE)                                                                              // :104-108
                 vis &= !cm::coneTail(q, cv, rad, VR);
             TR_STAMP(3);   // quotients + cone
+            bool accept = false, pair = false;
+            float depthSphere = 0.f;
             if (OCCLUSION && TABLE) {                                                              // :75-88 (Q4)
-                oq = cm::occTailQuad(q, cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_mipTab, a.quad.total);
+                const cm::OccQuad oq = cm::occTailQuad(q, cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_mipTab, a.quad.total);
+                accept = oq.accept; depthSphere = oq.depthSphere;
                 // The one 2-byte load of the lookup -- only for the lanes whose meshlet is still in the race and not
                 // accepted at the near plane (:48-49): the tests are pure, so skipping a lookup whose result cannot
-                // matter changes nothing, and a third fewer scattered requests reach the L1 (the kernel's bottleneck).
+                // matter changes nothing, and a third fewer scattered requests reach the L1.
                 const uint16_t* entry = reinterpret_cast<const uint16_t*>(a.quad.base) + oq.iq;
 #ifdef TR_NO_LOOKUP      /* experiment, results WRONG: what the kernel would cost if the lookups were free */
-                asm volatile("" : "+v"(footprintBits) : "v"(entry));
+                issueLookup(lk0[kSlot], lk1[kSlot], a.quad.base, a.quad.base, false);
+                asm volatile("" :: "v"(entry));
 #else
-                if (vis & !oq.accept)
-                    asm volatile("global_load_ushort %0, %1, off" : "+v"(footprintBits) : "v"(entry) : "memory");
+                issueLookup(lk0[kSlot], lk1[kSlot], entry, entry, vis & !oq.accept);
 #endif
-            }
-            if (OCCLUSION && !TABLE) {
-                os = cm::occTailTexel(q, cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_quadOff);
-                const _Float16* t0 = a.hzb.base + os.i0;                                          // two texel pairs (cm::loadTexelPair)
-                const _Float16* t1 = a.hzb.base + os.i1;
-                if (vis & !os.accept)
-                    asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "+v"(row0), "+v"(row1) : "v"(t0), "v"(t1) : "memory");
-            }
-            // prefetch step s + kRingSlots into this slot (past the batch: the padding entries, a harmless re-read of meshlet 0 that
-            // keeps the loads unconditional).  The slot's LDS reads above have returned: their values were used.
-            issueMeshletLoads(slot, a.meshlets, s_rec[r + 2 * kRingSlots].first, s_rec[r + 2 * kRingSlots].count, sub);
-            TR_STAMP(4);   // lookup + prefetch issue
-            // Loads are counted in order: "at most 2 outstanding" = everything before this step's prefetch has landed,
-            // whether or not the wave issued its lookup.
-            if (OCCLUSION && !TABLE) {
-                asm volatile("s_waitcnt vmcnt(2)" : "+v"(row0), "+v"(row1) :: "memory");
-                vis &= cm::occlusionResolve(os, row0, row1);
-            }
-            if (OCCLUSION && TABLE) {
-                asm volatile("s_waitcnt vmcnt(2)" : "+v"(footprintBits) :: "memory");
-                const float footprintMin = (float)__builtin_bit_cast(_Float16, (uint16_t)footprintBits);
-                const bool visO = oq.accept | (oq.depthSphere >= footprintMin);                    // :81
                 // A lookup whose footprint is NOT the table's (a zero bilinear weight) is only noted here and the
                 // meshlet is re-evaluated with the texel path after the batch (fixups below).  Rare.
                 if (__builtin_expect(__ballot(oq.slow) != 0ull, 0)) {
@@ -408,20 +438,53 @@ __global__ __launch_bounds__(kCullBlock) void meshletCullKernel(MeshletCullArgs 
                         if (idx < kSlowCap) s_slow[idx] = (r << 5) | sub;
                     }
                 }
-                vis &= visO;
             }
-            TR_STAMP(5);   // lookup wait + resolve
-            // :116,120 WavePrefix/ActiveCountBits: lanes 0-31 ran record 2s, lanes 32-63 record 2s+1, in meshlet order
-            const unsigned long long ballot = __ballot(vis);
-            const uint32_t mask = half ? (uint32_t)(ballot >> 32) : (uint32_t)ballot;
-            if (sub == 0) s_mask[r] = mask;             // LDS: the loop issues no stores to memory
-            TR_STAMP(6);   // ballot + mask store
+            if (OCCLUSION && !TABLE) {
+                const cm::OccSample os = cm::occTailTexel(q, cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_quadOff);
+                accept = os.accept; depthSphere = os.depthSphere; pair = os.pair;
+                issueLookup(lk0[kSlot], lk1[kSlot], a.hzb.base + os.i0, a.hzb.base + os.i1, vis & !os.accept);   // two texel pairs (cm::loadTexelPair)
+            }
+            // prefetch step s + kRingSlots into this slot (past the batch: the padding entries, a harmless re-read of meshlet 0 that
+            // keeps the loads unconditional).  The slot's LDS reads above have returned: their values were used.
+            issueMeshletLoads(slot, a.meshlets, s_rec[r + 2 * kRingSlots].first, s_rec[r + 2 * kRingSlots].count, sub);
+            TR_STAMP(4);   // lookup + prefetch issue
+            if (!OCCLUSION) {
+                resolve(r + 2u, vis, true, false, 0.f, 0u, 0u);
+            } else if (!kDefer) {
+                // Loads are counted in order: "at most 2 outstanding" = everything before this step's prefetch has landed.
+                asm volatile("s_waitcnt vmcnt(2)" : "+v"(lk0[kSlot]), "+v"(lk1[kSlot]) :: "memory");
+                TR_STAMP(5);   // lookup wait
+                resolve(r + 2u, vis, accept, pair, depthSphere, lk0[kSlot], lk1[kSlot]);
+            } else {
+                // the PREVIOUS step's lookup: younger than it are its step's prefetch (2), this step's lookup (kLk) and prefetch (2)
+                if (kLk == 1) asm volatile("s_waitcnt vmcnt(5)" : "+v"(lk0[kPrev]), "+v"(lk1[kPrev]) :: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" : "+v"(lk0[kPrev]), "+v"(lk1[kPrev]) :: "memory");
+                TR_STAMP(5);   // lookup wait
+                resolve(r, pVis, pAccept, pPair, pDepth, lk0[kPrev], lk1[kPrev]);                 // record r - 2 of the batch (r = 0, 1: the dummy)
+                pVis = vis; pAccept = accept; pPair = pair; pDepth = depthSphere;
+            }
+            TR_STAMP(6);   // resolve + ballot + mask store
         };
+        // Prime the ring.  kDefer: a lookup "of the step before the first" (lane 0, entry 0) goes where a step's lookup sits in
+        // the load order -- in front of the youngest slot's loads -- so that every step sees the same sequence; its resolve
+        // lands in s_mask[0], [1].
+#pragma unroll
+        for (uint32_t k = 0; k + 1 < kRingSlots; ++k)
+            issueMeshletLoads(ring + 2048u * k, a.meshlets, s_rec[2 * k + half].first, s_rec[2 * k + half].count, sub);
+        if (kDefer) {
+            const void* p = TABLE ? (const void*)a.quad.base : (const void*)a.hzb.base;
+            issueLookup(lk0[kRingSlots - 1u], lk1[kRingSlots - 1u], p, p, false);
+        }
+        issueMeshletLoads(ring + 2048u * (kRingSlots - 1u), a.meshlets, s_rec[2 * (kRingSlots - 1u) + half].first, s_rec[2 * (kRingSlots - 1u) + half].count, sub);
 #pragma unroll 1
         for (uint32_t s = 0; s < nSteps; s += kRingSlots) {
-            step(ring, s);
-            step(ring + 2048, s + 1);
-            if (kRingSlots == 3) step(ring + 4096, s + 2);
+            step(std::integral_constant<uint32_t, 0>{}, s);
+            step(std::integral_constant<uint32_t, 1>{}, s + 1);
+            if (kRingSlots == 3) step(std::integral_constant<uint32_t, 2>{}, s + 2);
+        }
+        if (kDefer) {                                    // the last step's lookup
+            asm volatile("s_waitcnt vmcnt(2)" : "+v"(lk0[kRingSlots - 1u]), "+v"(lk1[kRingSlots - 1u]) :: "memory");
+            resolve(2u * (nSteps - 1u) + half + 2u, pVis, pAccept, pPair, pDepth, lk0[kRingSlots - 1u], lk1[kRingSlots - 1u]);
         }
         TR_WAIT_VMCNT(0);                               // the last (padding) prefetches: nothing may land in the ring later
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -458,14 +521,14 @@ __global__ __launch_bounds__(kCullBlock) void meshletCullKernel(MeshletCullArgs 
                 if (nSlow <= kSlowCap) {                                             // patch single bits
                     if (lane < nSlow) {
                         const uint32_t e = s_slow[lane], r = e >> 5, m = e & 31u;
-                        if (exactVisible(r, m)) atomicOr(&s_mask[r], 1u << m);
-                        else atomicAnd(&s_mask[r], ~(1u << m));
+                        if (exactVisible(r, m)) atomicOr(&s_mask[r + 2u], 1u << m);
+                        else atomicAnd(&s_mask[r + 2u], ~(1u << m));
                     }
                 } else {                                                             // list overflow: redo the whole batch exactly
                     for (uint32_t s = 0; s < nSteps; ++s) {
                         const uint32_t r = 2 * s + half;
                         const unsigned long long ballot = __ballot(exactVisible(r, sub));
-                        if (sub == 0) s_mask[r] = half ? (uint32_t)(ballot >> 32) : (uint32_t)ballot;
+                        if (sub == 0) s_mask[r + 2u] = half ? (uint32_t)(ballot >> 32) : (uint32_t)ballot;
                     }
                 }
                 if (lane == 0) s_slowCount[wave] = 0;
@@ -476,7 +539,7 @@ __global__ __launch_bounds__(kCullBlock) void meshletCullKernel(MeshletCullArgs 
         // ---- the batch's 64 masks leave in one store (lane l: record l of the batch) ----------------------------
         {
             const uint32_t g = lane < kCullBatch ? s_gIdx[lane] : 0xFFFFFFFFu;
-            if (g < G && (lane >> 1) < nSteps) a.visMask[g] = s_mask[lane < kCullBatch ? lane : 0u];
+            if (g < G && (lane >> 1) < nSteps) a.visMask[g] = s_mask[(lane < kCullBatch ? lane : 0u) + 2u];
         }
     }
 #ifdef TR_STAMPS
@@ -1163,7 +1226,7 @@ int recordASMain(trhip::DispatchCtx& ctx)
     // workgroups to fill the chip and let them stride over the chunks.
     // As many workgroups per CU as the LDS allows (39.5 KB each: 13.5 KB of per-record data + 24 KB of staged MeshletData):
     // the kernel's pace is set by the bytes it keeps in flight (3 ring slots x 2 KB per wave), see issueMeshletLoads.
-    uint32_t blocksPerCU = 4u;
+    uint32_t blocksPerCU = TR_CULL_WAVES_PER_EU;
     if (const char* e = getenv("TRHIP_AS_BLOCKS_PER_CU")) blocksPerCU = (uint32_t)atoi(e) ? (uint32_t)atoi(e) : blocksPerCU;   // tuning experiments
     uint32_t grid = ctx.computeUnits() * blocksPerCU;
     const uint32_t needBlocks = (a.recordCapacity + kCullBatch * kCullWaves - 1) / (kCullBatch * kCullWaves);
