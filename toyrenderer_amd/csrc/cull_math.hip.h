@@ -29,6 +29,16 @@ __device__ __forceinline__ float div_(float a, float b) { return a / b; }
 #endif
 __device__ __forceinline__ float clamp_(float x, float lo, float hi) { return min_(max_(x, lo), hi); }
 
+// Lane masks.  A `bool` of the compiler lives in an SGPR pair too, but the moment its VALUE is wanted (a ballot that is
+// stored or combined, not just branched on) hipcc materialises it per lane (v_cndmask 0/1) and compares again -- two
+// vector instructions per ballot, one of them a compare (4.7 SIMD cycles: profiles/r3/valu_rate.txt).  The hot loop
+// therefore takes its predicates straight from the vector compares: one bit per lane, 0 for lanes outside EXEC, combined
+// with scalar instructions.  Every wave of the kernels that use these is full (EXEC = all ones), so `~m` is "not".
+typedef unsigned long long lmask;
+__device__ __forceinline__ lmask mLt(float a, float b) { lmask m; asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }   // a < b (false for NaN)
+__device__ __forceinline__ lmask mGe(float a, float b) { lmask m; asm("v_cmp_ge_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }   // a >= b (false for NaN)
+__device__ __forceinline__ lmask mLeU(uint32_t a, uint32_t b) { lmask m; asm("v_cmp_le_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
+
 // Two independent fp32 values in one 64-bit register pair: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 process both
 // in one issue slot (the hot kernel is VALU-issue bound).  Every packed operation below is the same IEEE operation
 // on each component as its scalar counterpart, so results do not change.
@@ -153,6 +163,11 @@ __device__ __forceinline__ bool frustumVisible(F3 c, float r, float fx, float fy
     bool a = fma_(c.z, fy, __builtin_fabsf(c.x) * fx) < r;
     bool b = fma_(c.z, fw, __builtin_fabsf(c.y) * fz) < r;
     return a & b;
+}
+
+__device__ __forceinline__ lmask frustumVisibleM(F3 c, float r, float fx, float fy, float fz, float fw)   // == frustumVisible, as a lane mask
+{
+    return mLt(fma_(c.z, fy, __builtin_fabsf(c.x) * fx), r) & mLt(fma_(c.z, fw, __builtin_fabsf(c.y) * fz), r);
 }
 
 // HZB (R16_FLOAT mip chain) as the kernels see it.
@@ -301,7 +316,7 @@ __device__ __forceinline__ uint32_t quadIndex(uint32_t offset, uint32_t blockRow
 // an exact integer), which the caller resolves with the texel path.
 struct OccQuad
 {
-    bool accept;              // :48-49
+    lmask accept;             // :48-49 (lane mask)
     bool slow;
     float depthSphere;        // :79
     uint32_t iq;              // table index (always in range: uv is clamped to [0,1] and NaN-free)
@@ -463,7 +478,7 @@ __device__ __forceinline__ F3 coneAxisCutoff(uint32_t packed, float* cutoff)
 #endif
 
 template <bool OCC, bool CONE>
-__device__ __forceinline__ void stepQuotients(bool active, F3 c, float r, uint32_t packed, const M33P& adj, float nearPlane, bool nearInRange, StepQuot& o)
+__device__ __forceinline__ void stepQuotients(lmask active, F3 c, float r, uint32_t packed, const M33P& adj, float nearPlane, bool nearInRange, StepQuot& o)
 {
     // active: the lane tests a meshlet.  The others (past the end of a record, records past the end of the list) run along
     // on whatever operands they hold, never reach an output and must not send the wave down the EXACT path.
@@ -513,8 +528,8 @@ __device__ __forceinline__ void stepQuotients(bool active, F3 c, float r, uint32
         uMax = max(max(__float_as_uint(st), __float_as_uint(sc)), uMax);
         mag = min_(mag, minAbs3(t.x, t.y, t.z));
     }
-    const bool safe = ((uMin >= kLo) & (uMax <= kHi) & (mag >= 0x1p-30f) & rOk & nearInRange) | !active;
-    if (__builtin_expect(__ballot(!safe) != 0ull, 0)) {
+    const bool safe = (uMin >= kLo) & (uMax <= kHi) & (mag >= 0x1p-30f) & rOk & nearInRange;
+    if (__builtin_expect((__builtin_amdgcn_ballot_w64(!safe) & active) != 0ull, 0)) {
         // ---- EXACT path (rare): the compiler's full square root / division sequences, as before ---------------------
         TR_PATH_COUNT(true);
         if (OCC) {
@@ -617,7 +632,7 @@ __device__ __forceinline__ OccQuad occTailQuad(const StepQuot& q, F3 c, float r,
                                                const uint4* mipTab, uint32_t quadTotal)
 {
     OccQuad o;
-    o.accept = (c.z - nearPlane) < r;                                  // :48-49
+    o.accept = mLt(c.z - nearPlane, r);                                // :48-49
     const v2f P = { P00, P11 };
     const v2f lo = occClampUv(q.mn, P), hi = occClampUv(q.mx, P);      // (ax, ay), (az, aw)
     const v2f wh = (hi - lo) * v2f{ (float)h.width, (float)h.height }; // :73-74
@@ -676,11 +691,11 @@ __device__ __forceinline__ OccSample occTailTexel(const StepQuot& q, F3 c, float
 }
 
 // basepass.hlsl:104-107 + ConeCull (culling.hlsli:84-87) from the normalised axis on; true = back-facing
-__device__ __forceinline__ bool coneTail(const StepQuot& q, F3 cv, float r, const M33P& viewRot)
+__device__ __forceinline__ lmask coneTail(const StepQuot& q, F3 cv, float r, const M33P& viewRot)
 {
     F3 axis = mulVecP(q.tn, viewRot);
     axis.z = -axis.z;
-    return dot3(cv, axis) >= fma_(q.cutoff, q.lenC, r);
+    return mGe(dot3(cv, axis), fma_(q.cutoff, q.lenC, r));
 }
 
 __device__ __forceinline__ M43 loadM43(const interop::Matrix& m)

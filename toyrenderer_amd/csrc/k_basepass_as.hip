@@ -92,9 +92,12 @@ struct RecordInfo                                 // per-record invariants parke
     float adjxy[6];                               // MakeAdjugateMatrix rows 0..2: (x, y) pairs
     float adjz[3];                                //                               z column
     float maxScale;
-    uint32_t first;                               // m_MeshletDataBufferIdx + m_MeshletGroupOffset (0 when count == 0)
-    uint32_t count;                               // lanes with meshletIdx < m_NumMeshlets (0..32)
+    uint32_t first;                               // m_MeshletDataBufferIdx + m_MeshletGroupOffset (0 when the record tests nothing)
+    uint32_t lastOff;                             // byte offset of the last 16-byte chunk of the record's MeshletData: 32 * count - 16
+                                                  // (count = lanes with meshletIdx < m_NumMeshlets, 1..32), or 0 for count 0
 };
+__device__ __forceinline__ uint32_t lastOffOf(uint32_t count) { return count ? 32u * count - 16u : 0u; }
+__device__ __forceinline__ uint32_t countOf(uint32_t lastOff) { return (lastOff + 16u) >> 5; }
 static_assert(sizeof(RecordInfo) == 96, "RecordInfo layout");
 
 __device__ __forceinline__ cm::M43P worldOf(const RecordInfo& ri)
@@ -158,18 +161,16 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 //
 // LDS layout of a ring slot (2 KB per wave): [0,512) record A chunks 0-31, [512,1024) record B chunks 0-31,
 // [1024,1536) record A chunks 32-63, [1536,2048) record B chunks 32-63.
-__device__ __forceinline__ void issueMeshletLoads(char* slotLds /* wave-uniform */, const MeshletData* meshlets, uint32_t firstIdx, uint32_t count, uint32_t sub)
+__device__ __forceinline__ void issueMeshletLoads(char* slotLds /* wave-uniform */, const MeshletData* meshlets, uint32_t firstIdx, uint32_t lastOff, uint32_t sub16 /* 16 * sub */)
 {
-    // Every lane always loads (chunks past the record's end re-read chunk 0): the number of loads in flight never
-    // depends on the data.
-    const uint32_t nChunks = count * 2u;
-    const uint32_t ja = sub < nChunks ? sub : 0u, jb = 32u + sub < nChunks ? 32u + sub : 0u;
+    // Every lane always loads (chunks past the record's end re-read its last chunk): the number of loads in flight never
+    // depends on the data, and nothing outside the record is read.
 #ifdef TR_EXP_NOMEM      /* experiment, results WRONG: every wave streams the same 2 KB (cache hits): the kernel without its HBM traffic */
     firstIdx &= 63u;
 #endif
     const char* p = reinterpret_cast<const char*>(meshlets + firstIdx);
-    const char* pa = p + 16u * ja;                                                   // basepass.hlsl:65
-    const char* pb = p + 16u * jb;
+    const char* pa = p + min(sub16, lastOff);                                        // basepass.hlsl:65
+    const char* pb = p + min(sub16 + 512u, lastOff);
     const uint32_t ldsOff = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)slotLds;
     // nt: the 1.8 GB stream is read once and must not evict the HZB table and the per-record data from the L2s
 #ifndef TR_DMA_POLICY_ID
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
     __shared__ uint4 s_mipTab[17];                     // table path: per-mip constants indexed by exponent + 1 (cm::occTailQuad)
     __shared__ uint32_t s_slowAll[kCullWaves][kSlowCap];
     __shared__ uint32_t s_slowCount[kCullWaves];
-    __shared__ uint32_t s_maskAll[kCullWaves][kCullBatch + 2];   // [0], [1]: where the deferred resolve of "the step before the first" lands
+    __shared__ __attribute__((aligned(8))) uint32_t s_maskAll[kCullWaves][kCullBatch + 2];   // [0], [1]: where the deferred resolve of "the step before the first" lands
     __shared__ __attribute__((aligned(16))) char s_ring[kCullWaves][kRingSlots][2048];   // per wave: the ring slots of staged MeshletData
 
     const uint32_t G = groupCount(a);
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
     // the fast arithmetic path wants nearPlane in [2^-20, 2^20] (cm::stepQuotients)
     const bool nearInRange = a.k.m_NearPlane >= 0x1p-20f && a.k.m_NearPlane <= 0x1p20f;
     if (tid < kCullWaves) s_slowCount[tid] = 0;
-    if (lane < 2 * kRingSlots) { s_recAll[wave][kCullBatch + lane].first = 0; s_recAll[wave][kCullBatch + lane].count = 0; }
+    if (lane < 2 * kRingSlots) { s_recAll[wave][kCullBatch + lane].first = 0; s_recAll[wave][kCullBatch + lane].lastOff = 0; }
     uint32_t* s_slow = s_slowAll[wave];
     uint32_t* s_mask = s_maskAll[wave];
     __syncthreads();                                                                 // the only workgroup barrier
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
         //      level of dependent loads here -- the entry itself was fetched while the previous batch ran ------
         {
             RecordInfo ri;
-            ri.count = 0; ri.first = 0; ri.maxScale = 0.f;
+            ri.lastOff = 0; ri.first = 0; ri.maxScale = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) ri.wxy[i] = 0.f;
 #pragma unroll
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
                 }
                 cnt = cnt < 32u ? cnt : 32u;
                 if (base + cnt > a.numMeshlets) cnt = 0;                             // never read outside the meshlet buffer
-                ri.count = cnt;
+                ri.lastOff = lastOffOf(cnt);
                 if (cnt) ri.first = (uint32_t)base;                                  // < numMeshlets <= 2^32 (recordASMain)
             }
             if (lane < kCullBatch) s_rec[lane] = ri;
@@ -348,6 +349,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
         // at the top, vmcnt(2) for the lookup.
         char* const ring = s_ring[__builtin_amdgcn_readfirstlane((int)wave)][0];
         const uint32_t ringOff = (sub < 16u ? 0u : 512u) + half * 512u + sub * 32u;  // this lane's meshlet inside a ring slot
+        const uint32_t sub16 = sub * 16u, subEnd = sub * 32u + 16u;                  // lane constants of the chunk addressing / the "active" test
         // The occlusion lookup of a step (TABLE: one 2-byte table entry; texel path: two texel pairs), issued for the lanes
         // still in the race -- and ALWAYS for lane 0 (any in-range address), so that the instruction issues whatever the
         // data: the hand-counted waits below rely on a fixed number of loads per step.
@@ -358,10 +360,11 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
         uint32_t lk0[kRingSlots], lk1[kRingSlots];
 #pragma unroll
         for (uint32_t k = 0; k < kRingSlots; ++k) { lk0[k] = 0u; lk1[k] = 0u; }
-        bool pVis = false, pAccept = false, pPair = false;
+        cm::lmask pVis = 0ull, pAccept = 0ull;
+        bool pPair = false;
         float pDepth = 0.f;
-        auto issueLookup = [&](uint32_t& w0, uint32_t& w1, const void* p0, const void* p1, bool want) {
-            const unsigned long long m = __ballot(want) | 1ull;
+        auto issueLookup = [&](uint32_t& w0, uint32_t& w1, const void* p0, const void* p1, cm::lmask want) {
+            const unsigned long long m = want | 1ull;
             unsigned long long sv;
             if (TABLE)
                 asm volatile("s_mov_b64 %[sv], exec\n\ts_and_b64 exec, exec, %[m]\n\tglobal_load_ushort %[d], %[a], off\n\ts_mov_b64 exec, %[sv]"
@@ -370,21 +373,21 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
                 asm volatile("s_mov_b64 %[sv], exec\n\ts_and_b64 exec, exec, %[m]\n\tglobal_load_dword %[d0], %[a0], off\n\tglobal_load_dword %[d1], %[a1], off\n\ts_mov_b64 exec, %[sv]"
                              : [d0] "+v"(w0), [d1] "+v"(w1), [sv] "=&s"(sv) : [a0] "v"(p0), [a1] "v"(p1), [m] "s"(m) : "memory", "scc");
         };
-        // the mask of batch record r lives at s_mask[r + 2]
-        auto resolve = [&](uint32_t r2, bool vis, bool accept, bool pair, float depthSphere, uint32_t w0, uint32_t w1) {
-            bool visO;
-            if (TABLE) {
-                const float footprintMin = (float)__builtin_bit_cast(_Float16, (uint16_t)w0);
-                visO = accept | (depthSphere >= footprintMin);                                     // :81
-            } else {
-                cm::OccSample os; os.accept = accept; os.pair = pair; os.depthSphere = depthSphere; os.i0 = os.i1 = 0;
-                visO = cm::occlusionResolve(os, w0, w1);
+        // The masks of the two records of a step -- :116,120 WavePrefix/ActiveCountBits: lanes 0-31 ran record 2s, lanes 32-63
+        // record 2s + 1, in meshlet order -- are the two halves of the step's lane mask; lane 0 stores both (record r of the
+        // batch lives at s_mask[r + 2]: pair = 2s + 2, even).  LDS: the loop issues no stores to memory.
+        auto resolve = [&](uint32_t pair, cm::lmask vis, cm::lmask accept, bool pairCol, float depthSphere, uint32_t w0, uint32_t w1) {
+            if (OCCLUSION) {
+                if (TABLE) {
+                    const float footprintMin = (float)__builtin_bit_cast(_Float16, (uint16_t)w0);
+                    vis &= accept | cm::mGe(depthSphere, footprintMin);                            // :81
+                } else {
+                    const float d00 = cm::texelLo(w0), d10 = cm::texelLo(w1);                      // cm::occlusionResolve
+                    const float d01 = pairCol ? cm::texelHi(w0) : d00, d11 = pairCol ? cm::texelHi(w1) : d10;
+                    vis &= accept | cm::mGe(depthSphere, cm::min_(cm::min_(cm::min_(d00, d01), d10), d11));
+                }
             }
-            vis &= visO;
-            // :116,120 WavePrefix/ActiveCountBits: lanes 0-31 ran record 2s, lanes 32-63 record 2s+1, in meshlet order
-            const unsigned long long ballot = __ballot(vis);
-            const uint32_t mask = half ? (uint32_t)(ballot >> 32) : (uint32_t)ballot;
-            if (sub == 0) s_mask[r2] = mask;            // LDS: the loop issues no stores to memory
+            if (lane == 0) *reinterpret_cast<uint2*>(&s_mask[pair]) = make_uint2((uint32_t)vis, (uint32_t)(vis >> 32));
         };
         auto step = [&](auto kc, uint32_t s) {
             constexpr uint32_t kSlot = decltype(kc)::value, kPrev = (kSlot + kRingSlots - 1u) % kRingSlots;
@@ -399,23 +402,24 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
             const v4f sph = *reinterpret_cast<const v4f*>(slot + ringOff);
             const uint32_t cone = *reinterpret_cast<const uint32_t*>(slot + ringOff + 16u);
             const float4 sphere = make_float4(sph.x, sph.y, sph.z, sph.w);
-            const bool active = sub < ri.count;                                                    // :62-63
-            bool vis = active;
+            const cm::lmask active = cm::mLeU(subEnd, ri.lastOff);                                 // :62-63 meshletIdx < numMeshlets
+            cm::lmask vis = active;
             const cm::M43P W = worldOf(ri);
             const cm::F3 cw = cm::mulPointP({ sphere.x, sphere.y, sphere.z }, W);                  // :67
             const cm::F3 cv = cm::toViewP(cw, VP);                                                 // :68-69
             const float rad = sphere.w * ri.maxScale;                                              // :71
             if (FRUSTUM)
-                vis &= cm::frustumVisible(cv, rad, a.k.m_Frustum.x, a.k.m_Frustum.y, a.k.m_Frustum.z, a.k.m_Frustum.w); // :73
+                vis &= cm::frustumVisibleM(cv, rad, a.k.m_Frustum.x, a.k.m_Frustum.y, a.k.m_Frustum.z, a.k.m_Frustum.w); // :73
             TR_STAMP(2);   // wait for data + transform + frustum
             // every square root and division of the step (:56-62, :79, normalize :103): fast when the whole wave can
             cm::StepQuot q;
             if (OCCLUSION || CONE)
                 cm::stepQuotients<OCCLUSION, CONE>(active, cv, rad, cone, adjugateOf(ri), a.k.m_NearPlane, nearInRange, q);
             if (CONE)                                                                              // :104-108
-                vis &= !cm::coneTail(q, cv, rad, VR);
+                vis &= ~cm::coneTail(q, cv, rad, VR);
             TR_STAMP(3);   // quotients + cone
-            bool accept = false, pair = false;
+            cm::lmask accept = 0ull;
+            bool pair = false;
             float depthSphere = 0.f;
             if (OCCLUSION && TABLE) {                                                              // :75-88 (Q4)
                 const cm::OccQuad oq = cm::occTailQuad(q, cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_mipTab, a.quad.total);
@@ -425,10 +429,10 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
                 // matter changes nothing, and a third fewer scattered requests reach the L1.
                 const uint16_t* entry = reinterpret_cast<const uint16_t*>(a.quad.base) + oq.iq;
 #ifdef TR_NO_LOOKUP      /* experiment, results WRONG: what the kernel would cost if the lookups were free */
-                issueLookup(lk0[kSlot], lk1[kSlot], a.quad.base, a.quad.base, false);
+                issueLookup(lk0[kSlot], lk1[kSlot], a.quad.base, a.quad.base, 0ull);
                 asm volatile("" :: "v"(entry));
 #else
-                issueLookup(lk0[kSlot], lk1[kSlot], entry, entry, vis & !oq.accept);
+                issueLookup(lk0[kSlot], lk1[kSlot], entry, entry, vis & ~oq.accept);
 #endif
                 // A lookup whose footprint is NOT the table's (a zero bilinear weight) is only noted here and the
                 // meshlet is re-evaluated with the texel path after the batch (fixups below).  Rare.
@@ -441,26 +445,27 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
             }
             if (OCCLUSION && !TABLE) {
                 const cm::OccSample os = cm::occTailTexel(q, cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_quadOff);
-                accept = os.accept; depthSphere = os.depthSphere; pair = os.pair;
-                issueLookup(lk0[kSlot], lk1[kSlot], a.hzb.base + os.i0, a.hzb.base + os.i1, vis & !os.accept);   // two texel pairs (cm::loadTexelPair)
+                accept = cm::mLt(cv.z - a.k.m_NearPlane, rad);                                     // == os.accept (:48-49)
+                depthSphere = os.depthSphere; pair = os.pair;
+                issueLookup(lk0[kSlot], lk1[kSlot], a.hzb.base + os.i0, a.hzb.base + os.i1, vis & ~accept);   // two texel pairs (cm::loadTexelPair)
             }
             // prefetch step s + kRingSlots into this slot (past the batch: the padding entries, a harmless re-read of meshlet 0 that
             // keeps the loads unconditional).  The slot's LDS reads above have returned: their values were used.
-            issueMeshletLoads(slot, a.meshlets, s_rec[r + 2 * kRingSlots].first, s_rec[r + 2 * kRingSlots].count, sub);
+            issueMeshletLoads(slot, a.meshlets, s_rec[r + 2 * kRingSlots].first, s_rec[r + 2 * kRingSlots].lastOff, sub16);
             TR_STAMP(4);   // lookup + prefetch issue
             if (!OCCLUSION) {
-                resolve(r + 2u, vis, true, false, 0.f, 0u, 0u);
+                resolve(2u * s + 2u, vis, 0ull, false, 0.f, 0u, 0u);
             } else if (!kDefer) {
                 // Loads are counted in order: "at most 2 outstanding" = everything before this step's prefetch has landed.
                 asm volatile("s_waitcnt vmcnt(2)" : "+v"(lk0[kSlot]), "+v"(lk1[kSlot]) :: "memory");
                 TR_STAMP(5);   // lookup wait
-                resolve(r + 2u, vis, accept, pair, depthSphere, lk0[kSlot], lk1[kSlot]);
+                resolve(2u * s + 2u, vis, accept, pair, depthSphere, lk0[kSlot], lk1[kSlot]);
             } else {
                 // the PREVIOUS step's lookup: younger than it are its step's prefetch (2), this step's lookup (kLk) and prefetch (2)
                 if (kLk == 1) asm volatile("s_waitcnt vmcnt(5)" : "+v"(lk0[kPrev]), "+v"(lk1[kPrev]) :: "memory");
                 else asm volatile("s_waitcnt vmcnt(6)" : "+v"(lk0[kPrev]), "+v"(lk1[kPrev]) :: "memory");
                 TR_STAMP(5);   // lookup wait
-                resolve(r, pVis, pAccept, pPair, pDepth, lk0[kPrev], lk1[kPrev]);                 // record r - 2 of the batch (r = 0, 1: the dummy)
+                resolve(2u * s, pVis, pAccept, pPair, pDepth, lk0[kPrev], lk1[kPrev]);            // the records of step s - 1 (s = 0: the dummy pair)
                 pVis = vis; pAccept = accept; pPair = pair; pDepth = depthSphere;
             }
             TR_STAMP(6);   // resolve + ballot + mask store
@@ -470,12 +475,12 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
         // lands in s_mask[0], [1].
 #pragma unroll
         for (uint32_t k = 0; k + 1 < kRingSlots; ++k)
-            issueMeshletLoads(ring + 2048u * k, a.meshlets, s_rec[2 * k + half].first, s_rec[2 * k + half].count, sub);
+            issueMeshletLoads(ring + 2048u * k, a.meshlets, s_rec[2 * k + half].first, s_rec[2 * k + half].lastOff, sub16);
         if (kDefer) {
             const void* p = TABLE ? (const void*)a.quad.base : (const void*)a.hzb.base;
-            issueLookup(lk0[kRingSlots - 1u], lk1[kRingSlots - 1u], p, p, false);
+            issueLookup(lk0[kRingSlots - 1u], lk1[kRingSlots - 1u], p, p, 0ull);
         }
-        issueMeshletLoads(ring + 2048u * (kRingSlots - 1u), a.meshlets, s_rec[2 * (kRingSlots - 1u) + half].first, s_rec[2 * (kRingSlots - 1u) + half].count, sub);
+        issueMeshletLoads(ring + 2048u * (kRingSlots - 1u), a.meshlets, s_rec[2 * (kRingSlots - 1u) + half].first, s_rec[2 * (kRingSlots - 1u) + half].lastOff, sub16);
 #pragma unroll 1
         for (uint32_t s = 0; s < nSteps; s += kRingSlots) {
             step(std::integral_constant<uint32_t, 0>{}, s);
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
         }
         if (kDefer) {                                    // the last step's lookup
             asm volatile("s_waitcnt vmcnt(2)" : "+v"(lk0[kRingSlots - 1u]), "+v"(lk1[kRingSlots - 1u]) :: "memory");
-            resolve(2u * (nSteps - 1u) + half + 2u, pVis, pAccept, pPair, pDepth, lk0[kRingSlots - 1u], lk1[kRingSlots - 1u]);
+            resolve(2u * nSteps, pVis, pAccept, pPair, pDepth, lk0[kRingSlots - 1u], lk1[kRingSlots - 1u]);
         }
         TR_WAIT_VMCNT(0);                               // the last (padding) prefetches: nothing may land in the ring later
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
                 // exact visibility of meshlet m of batch record r (all tests, texel path for the HZB lookup)
                 auto exactVisible = [&](uint32_t r, uint32_t m) -> bool {
                     const RecordInfo& ri = s_rec[r];
-                    if (m >= ri.count) return false;
+                    if (m >= countOf(ri.lastOff)) return false;
                     const float4* p = reinterpret_cast<const float4*>(a.meshlets + ri.first);
                     const float4 sphere = p[2u * m];
                     const uint32_t cone = __float_as_uint(p[2u * m + 1u].x);
