@@ -64,6 +64,7 @@ def main():
     ap.add_argument("-D", action="append", default=[])
     ap.add_argument("--asm", help="use this assembly file instead of compiling")
     ap.add_argument("--dump", action="store_true", help="print the traced instructions")
+    ap.add_argument("--mode", default="cont", choices=["cont", "alone"], help="which instantiation of the body: continuous mode (default) or stand-alone batches")
     args = ap.parse_args()
     if args.asm:
         text = open(args.asm).read()
@@ -76,10 +77,10 @@ def main():
     sym = "meshletCullKernelI" + b(args.flags & 1) + b(args.flags & 2) + b(args.flags & 4) + b(args.table) + "EEv"
     lines = text.split("\n")
     start = next(i for i, l in enumerate(lines) if sym in l and re.match(r"^_Z\S+:", l))
-    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end")) - 1
     # resource lines after the body
     meta = {}
-    for l in lines[end:end + 80]:
+    for l in lines[end:end + 120]:
         m = re.match(r"\s*;\s*(NumVgprs|NumSgprs|Occupancy|LDSByteSize|ScratchSize|NumAgprs|TotalNumVgprs):\s*(\d+)", l)
         if m:
             meta[m.group(1)] = int(m.group(2))
@@ -93,15 +94,17 @@ def main():
     # first vmcnt wait that follows a label; find loop headers by their comment
     headers = [i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l) and ("Parent Loop" in l or "This Inner Loop" in l or "=>This Loop Header" in l)]
     dma = [i for i, l in enumerate(body) if "global_load_lds" in l]
-    cand = None
+    cands = []
     for h in headers:
         if "Parent Loop" not in body[h] and "Inner Loop" not in body[h]:
             continue
         nxt = [d for d in dma if d > h]
-        if nxt and nxt[0] - h < 400:
-            cand = h
-            break
-    assert cand is not None, "main loop not found"
+        nxt_header = [x for x in headers if x > h]
+        if nxt and nxt[0] - h < 600 and (not nxt_header or nxt[0] < nxt_header[0]):
+            cands.append(h)
+    assert cands, "main loop not found"
+    # the kernel body exists twice: batches that stand alone (record order) first, continuous mode (tile-ordered list) last
+    cand = cands[0] if args.mode == "alone" else cands[-1]
     header = re.match(r"^(\.LBB\d+_\d+):", body[cand]).group(1)
     counts = collections.Counter()
     mnems = collections.Counter()
@@ -139,7 +142,7 @@ def main():
     nd = sum(1 for t in trace if t.startswith("global_load_lds"))
     steps = nd // 2
     valu = sum(v for k, v in counts.items() if k.startswith("VALU"))
-    print(f"kernel meshletCullKernel<{args.flags & 1},{(args.flags >> 1) & 1},{(args.flags >> 2) & 1},{args.table}>  defines {args.D}")
+    print(f"kernel meshletCullKernel<{args.flags & 1},{(args.flags >> 1) & 1},{(args.flags >> 2) & 1},{args.table}>  body: {args.mode}  defines {args.D}")
     print("registers / LDS:", meta)
     print(f"hot path of one trip round the main loop: {len(trace)} instructions = {steps} steps of 64 meshlets")
     print(f"per step: {valu / steps:.1f} VALU, {counts['SALU'] / steps:.1f} SALU (+ {counts['SALU branch'] / steps:.1f} branches), "
