@@ -516,3 +516,66 @@ def test_hostile_operands_take_the_exact_arithmetic_path(dev, oracle, flags, tab
     finally:
         drv.release()
         gs.release()
+
+
+@pytest.mark.parametrize("flags,table", [(4, False), (5, False), (7, False), (7, True), (6, True)])
+def test_cone_test_at_its_decision_boundary(dev, oracle, flags, table):
+    """The cull kernel decides the cone test from t * rsq(t.t) and c.c * rsq(c.c) (a few ulp, no division) unless a lane
+    is within 2^-18 of the boundary dot(c, axis) = cutoff * |c| + r, in which case its wave redoes the test with the exact
+    square roots and divisions (cm::coneBack).  Here the radii of most meshlets are PUT on that boundary: the radius
+    that makes the two sides equal (evaluated in float64 from the float32 inputs), moved by 0, +-1, +-2, ... +-10^5 ulp,
+    so that lanes sit exactly on it, a few ulp beside it, at the edge of the 2^-18 band and outside -- in the same waves
+    as ordinary meshlets.  Bit-exact against the oracle like every other case."""
+    from toyrenderer_amd.frame import FrameDriver, GpuScene
+    rng = np.random.default_rng(900 + flags)
+    spec = synth.SceneSpec(num_meshes=600, num_instances=600, meshlets_lod0=64, max_lods=1, seed=777, nonuniform_scale_fraction=0.3,
+                           unique=True)                          # every instance its own meshlets: the radii below are per instance
+    scene = synth.make_scene(spec)
+    inst, ml, md = scene.instances, scene.meshlets, scene.meshData
+    view = synth.make_view(eye=(0.3, -0.2, 0.5), yaw=0.03, render=(1280, 720))
+    V = view.worldToView.astype(np.float64)
+    moved = 0
+    steps = np.array([0, 1, -1, 2, -2, 3, -3, 5, -5, 16, -16, 50, -50, 200, -200, 1000, -1000, 10 ** 4, -10 ** 4, 10 ** 5, -10 ** 5], np.int64)
+    for i in range(len(inst)):
+        W = inst["m_WorldMatrix"][i].astype(np.float64)
+        lod = md["m_MeshLODDatas"][inst["m_MeshDataIdx"][i]][0]
+        b, n = int(lod["m_MeshletDataBufferIdx"]), int(lod["m_NumMeshlets"])
+        sph = ml["m_BoundingSphere"][b:b + n].astype(np.float64)
+        packed = ml["m_ConeAxisAndCutoff"][b:b + n]
+        c = np.concatenate([sph[:, :3], np.ones((n, 1))], axis=1) @ W @ V
+        c = c[:, :3] * np.array([1.0, 1.0, -1.0])                                               # basepass.hlsl:68-69
+        by = np.stack([(packed >> s) & 0xFF for s in (0, 8, 16, 24)], axis=1).astype(np.float64) / 255.0
+        a = by[:, :3] * 2.0 - 1.0                                                                # :92-99
+        R3 = W[:3, :3]
+        adj = np.stack([np.cross(R3[1], R3[2]), np.cross(R3[2], R3[0]), np.cross(R3[0], R3[1])])  # toyrenderer_common.hlsli:124-132
+        t = a @ adj
+        tl = np.linalg.norm(t, axis=1)
+        ok = tl > 1e-6
+        axis = (t / np.where(ok, tl, 1.0)[:, None]) @ V[:3, :3] * np.array([1.0, 1.0, -1.0])    # :103-104
+        scale = np.sqrt(max(R3[0] @ R3[0], R3[1] @ R3[1], R3[2] @ R3[2]))                        # :134-140
+        r_star = (np.einsum("ij,ij->i", c, axis) - by[:, 3] * np.linalg.norm(c, axis=1)) / scale  # sphere.w that puts the meshlet ON the boundary
+        take = ok & (r_star > 1e-3) & (r_star < 50.0) & (rng.random(n) < 0.8)
+        w = r_star.astype(np.float32)
+        bits = w.view(np.int32).astype(np.int64) + rng.choice(steps, n)
+        w = bits.astype(np.int32).view(np.float32)
+        ml["m_BoundingSphere"][b:b + n, 3] = np.where(take, w, ml["m_BoundingSphere"][b:b + n, 3])
+        moved += int(take.sum())
+    assert moved > 5000, moved
+    d_prev = synth.gen_depth(view, num_occluders=40, seed=15, scale=3.0)
+    d_cur = synth.gen_depth(view, num_occluders=40, seed=16, scale=3.0)
+    cap = 1 << 19 if table else 65535
+    gs = GpuScene(dev, inst, md, ml, scene.opaqueIds, scene.alphaMaskIds)
+    drv = FrameDriver(dev, gs, view, record_capacity=cap, culling_flags=flags)
+    hzb = _oracle_hzb(oracle, view, d_prev)
+    _upload_hzb(drv, hzb)
+    drv.depth.upload_mip(0, d_cur)
+    try:
+        drv.record()
+        drv.run()
+        got = drv.results()
+        ref = oracle.frame(scene.as_oracle(), view.as_dict(), hzb, d_cur, cullingFlags=flags, maxGroups=cap, record_capacity=cap)
+        _compare_frame(got, ref)
+        assert int(ref.meshletsTested[0]) > 5000 and 0 < int(ref.drawArgs[0][0]) < int(ref.meshletsTested[0])
+    finally:
+        drv.release()
+        gs.release()

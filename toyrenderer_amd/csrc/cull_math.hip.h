@@ -37,6 +37,7 @@ __device__ __forceinline__ float clamp_(float x, float lo, float hi) { return mi
 typedef unsigned long long lmask;
 __device__ __forceinline__ lmask mLt(float a, float b) { lmask m; asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }   // a < b (false for NaN)
 __device__ __forceinline__ lmask mGe(float a, float b) { lmask m; asm("v_cmp_ge_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }   // a >= b (false for NaN)
+__device__ __forceinline__ lmask mAbsGt(float a, float b) { lmask m; asm("v_cmp_gt_f32_e64 %0, |%1|, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }   // |a| > b (false for NaN)
 __device__ __forceinline__ lmask mLeU(uint32_t a, uint32_t b) { lmask m; asm("v_cmp_le_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
 
 // Two independent fp32 values in one 64-bit register pair: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 process both
@@ -411,6 +412,7 @@ struct StepQuot
     float depthSphere;        // nearPlane / (c.z - r)                  culling.hlsli:79
     float lenC;               // length(c)                              culling.hlsli:86
     float cutoff;             // cone cutoff byte / 255                 basepass.hlsl:105
+    bool coneExact;           // wave-uniform: tn and lenC are the correctly rounded values (else: within 5 ulp, see coneBack)
 };
 
 __device__ __forceinline__ v2f rcpRefined2(v2f d)                       // Fma1 of the fdiv expansion: depends on d only
@@ -471,14 +473,24 @@ __device__ __forceinline__ F3 coneAxisCutoff(uint32_t packed, float* cutoff)
     return { a01.x, a01.y, fma_(q23.x, 2.0f, -1.0f) };
 }
 
+// The same through a 256-entry table in LDS, entry x = { fma(x / 255, 2, -1), x / 255 } computed with the arithmetic above
+// (coneTableEntry): four byte-indexed reads instead of 4 conversions + 7 packed operations per meshlet.
+__device__ __forceinline__ float2 coneTableEntry(uint32_t x) { const float q = u8Unorm(x); return make_float2(fma_(q, 2.0f, -1.0f), q); }
+__device__ __forceinline__ F3 coneAxisCutoffLds(uint32_t packed, float* cutoff, const float2* tab)
+{
+    *cutoff = tab[packed >> 24].y;
+    return { tab[packed & 0xFFu].x, tab[(packed >> 8) & 0xFFu].x, tab[(packed >> 16) & 0xFFu].x };
+}
+
 #ifdef TR_COUNT_PATHS
 #define TR_PATH_COUNT(exact) do { if ((threadIdx.x & 63u) == 0) atomicAdd(&g_pathCount[(exact) ? 1 : 0], 1ull); } while (0)
 #else
 #define TR_PATH_COUNT(exact) do {} while (0)
 #endif
 
-template <bool OCC, bool CONE>
-__device__ __forceinline__ void stepQuotients(lmask active, F3 c, float r, uint32_t packed, const M33P& adj, float nearPlane, bool nearInRange, StepQuot& o)
+template <bool OCC, bool CONE, bool CONETAB = false>
+__device__ __forceinline__ void stepQuotients(lmask active, F3 c, float r, uint32_t packed, const M33P& adj, float nearPlane, bool nearInRange, StepQuot& o,
+                                              const float2* coneTab = nullptr /* CONETAB: LDS, coneTableEntry() per byte value */)
 {
     // active: the lane tests a meshlet.  The others (past the end of a record, records past the end of the list) run along
     // on whatever operands they hold, never reach an output and must not send the wave down the EXACT path.
@@ -489,7 +501,7 @@ __device__ __forceinline__ void stepQuotients(lmask active, F3 c, float r, uint3
     float st = 1.0f, sc = 1.0f;
     o.cutoff = 0.0f;
     if (CONE) {
-        const F3 a = coneAxisCutoff(packed, &o.cutoff);
+        const F3 a = CONETAB ? coneAxisCutoffLds(packed, &o.cutoff, coneTab) : coneAxisCutoff(packed, &o.cutoff);
         t = mulVecP(a, adj);                                           // basepass.hlsl:103 mul(axis, adjugate)
         st = dot3(t, t);
         sc = dot3(c, c);                                               // culling.hlsli:86 length(center)^2
@@ -506,7 +518,8 @@ __device__ __forceinline__ void stepQuotients(lmask active, F3 c, float r, uint3
     // ---- optimistic: the fast square roots and what hangs on them ---------------------------------------------------
     v2f vv = { 1.0f, 1.0f }, lens = { 1.0f, 1.0f };
     if (OCC) vv = sqrtSeq2(vArg);                                      // :56, :60  vx, vy
-    if (CONE) lens = sqrtSeq2(v2f{ st, sc });                          // length(t), length(c)
+    // 1 / length(t), 1 / length(c) to 1 ulp: all the FAST path needs of the two lengths (coneBack)
+    const v2f rlen = CONE ? v2f{ __builtin_amdgcn_rsqf(st), __builtin_amdgcn_rsqf(sc) } : v2f{ 1.0f, 1.0f };
     v2f n1 = cxy, d1 = cxy, n2 = cxy, d2 = cxy;
     if (OCC) {
         n1 = fma2(vv, cxy, splat2(-crz)); d1 = fma2(vv, czz, cr);      // :57, :61
@@ -526,12 +539,13 @@ __device__ __forceinline__ void stepQuotients(lmask active, F3 c, float r, uint3
     if (CONE) {
         uMin = min(min(__float_as_uint(st), __float_as_uint(sc)), uMin);
         uMax = max(max(__float_as_uint(st), __float_as_uint(sc)), uMax);
-        mag = min_(mag, minAbs3(t.x, t.y, t.z));
     }
     const bool safe = (uMin >= kLo) & (uMax <= kHi) & (mag >= 0x1p-30f) & rOk & nearInRange;
+    o.coneExact = false;
     if (__builtin_expect((__builtin_amdgcn_ballot_w64(!safe) & active) != 0ull, 0)) {
         // ---- EXACT path (rare): the compiler's full square root / division sequences, as before ---------------------
         TR_PATH_COUNT(true);
+        o.coneExact = true;
         if (OCC) {
             vv = sqrt2(vArg);
             o.mn = div2(fma2(vv, cxy, splat2(-crz)), fma2(vv, czz, cr));
@@ -554,31 +568,38 @@ __device__ __forceinline__ void stepQuotients(lmask active, F3 c, float r, uint3
         TR_PATH_COUNT(false);
 #define TR_STAGE() __builtin_amdgcn_sched_barrier(0x0094)              /* SALU, VMEM and DS may cross; VALU may not */
         if (OCC && CONE) {
-            const v2f d3 = { lens.x, dz }, dl = splat2(lens.x);
-            const v2f n3 = { t.x, t.y }, n4 = { t.z, nearPlane };
+            // the four projection quotients as two packed chains, near / (z - r) as a plain one; the cone's normalisation and
+            // length(c) are NOT divided / rooted exactly here: t * (1 / length(t)) and c.c * (1 / length(c)) to a few ulp,
+            // which decides the cone test for every lane that is not within 2^-18 of its boundary (coneBack)
             const v2f ra = { __builtin_amdgcn_rcpf(d1.x), __builtin_amdgcn_rcpf(d1.y) };
             const v2f rb = { __builtin_amdgcn_rcpf(d2.x), __builtin_amdgcn_rcpf(d2.y) };
-            const v2f rc = { __builtin_amdgcn_rcpf(d3.x), __builtin_amdgcn_rcpf(d3.y) };
+            const float rc = __builtin_amdgcn_rcpf(dz);
             TR_STAGE();
-            const v2f ea = fma2(-d1, ra, splat2(1.0f)), eb = fma2(-d2, rb, splat2(1.0f)), ec = fma2(-d3, rc, splat2(1.0f));
+            const v2f ea = fma2(-d1, ra, splat2(1.0f)), eb = fma2(-d2, rb, splat2(1.0f));
+            const float ec = fma_(-dz, rc, 1.0f);
             TR_STAGE();
-            const v2f r1 = fma2(ea, ra, ra), r2 = fma2(eb, rb, rb), r3 = fma2(ec, rc, rc);
-            const v2f rl = splat2(r3.x);
+            const v2f r1 = fma2(ea, ra, ra), r2 = fma2(eb, rb, rb);
+            const float r3 = fma_(ec, rc, rc);
             TR_STAGE();
-            const v2f qa = n1 * r1, qb = n2 * r2, qc = n3 * rl, qd = n4 * r3;
+            const v2f qa = n1 * r1, qb = n2 * r2;
+            const float qc = nearPlane * r3;
+            const v2f txy = v2f{ t.x, t.y } * splat2(rlen.x);
             TR_STAGE();
-            const v2f fa = fma2(-d1, qa, n1), fb = fma2(-d2, qb, n2), fc = fma2(-dl, qc, n3), fd = fma2(-d3, qd, n4);
+            const v2f fa = fma2(-d1, qa, n1), fb = fma2(-d2, qb, n2);
+            const float fc = fma_(-dz, qc, nearPlane);
+            const v2f tzl = v2f{ t.z, sc } * rlen;                     // t.z / length(t), length(c) = c.c / length(c)
             TR_STAGE();
-            const v2f ga = fma2(fa, r1, qa), gb = fma2(fb, r2, qb), gc = fma2(fc, rl, qc), gd = fma2(fd, r3, qd);
+            const v2f ga = fma2(fa, r1, qa), gb = fma2(fb, r2, qb);
+            const float gc = fma_(fc, r3, qc);
             TR_STAGE();
-            const v2f ha = fma2(-d1, ga, n1), hb = fma2(-d2, gb, n2), hc = fma2(-dl, gc, n3), hd = fma2(-d3, gd, n4);
+            const v2f ha = fma2(-d1, ga, n1), hb = fma2(-d2, gb, n2);
+            const float hc = fma_(-dz, gc, nearPlane);
             TR_STAGE();
             o.mn = fma2(ha, r1, ga); o.mx = fma2(hb, r2, gb);
-            const v2f txy = fma2(hc, rl, gc), tzq = fma2(hd, r3, gd);
+            o.depthSphere = fma_(hc, r3, gc);
             TR_STAGE();
-            o.tn = { txy.x, txy.y, tzq.x };
-            o.depthSphere = tzq.y;
-            o.lenC = lens.y;
+            o.tn = { txy.x, txy.y, tzl.x };
+            o.lenC = tzl.y;
         } else if (OCC) {
             const v2f ra = { __builtin_amdgcn_rcpf(d1.x), __builtin_amdgcn_rcpf(d1.y) };
             const v2f rb = { __builtin_amdgcn_rcpf(d2.x), __builtin_amdgcn_rcpf(d2.y) };
@@ -605,11 +626,10 @@ __device__ __forceinline__ void stepQuotients(lmask active, F3 c, float r, uint3
             o.mn = fma2(ha, r1, ga); o.mx = fma2(hb, r2, gb);
             o.depthSphere = fma_(hc, r3, gc);
         } else if (CONE) {
-            const float r3 = rcpRefined1(lens.x);
-            const v2f txy = quotient2(v2f{ t.x, t.y }, splat2(lens.x), splat2(r3));
-            o.tn = { txy.x, txy.y, quotient1(t.z, lens.x, r3) };
+            const v2f txy = v2f{ t.x, t.y } * splat2(rlen.x), tzl = v2f{ t.z, sc } * rlen;
+            o.tn = { txy.x, txy.y, tzl.x };
             o.depthSphere = 0.0f;
-            o.lenC = lens.y;
+            o.lenC = tzl.y;
         } else {
             o.depthSphere = 0.0f;
         }
@@ -690,12 +710,46 @@ __device__ __forceinline__ OccSample occTailTexel(const StepQuot& q, F3 c, float
     return o;
 }
 
-// basepass.hlsl:104-107 + ConeCull (culling.hlsli:84-87) from the normalised axis on; true = back-facing
-__device__ __forceinline__ lmask coneTail(const StepQuot& q, F3 cv, float r, const M33P& viewRot)
+// basepass.hlsl:104-107 + ConeCull (culling.hlsli:84-87) from the normalised axis on; lane mask of the back-facing meshlets.
+//
+// FILTERED PREDICATE.  The reference's test is  D >= R  with  D = dot(c, mul(normalize(t), V)),  R = cutoff * length(c) + r,
+// every '/' and sqrt correctly rounded.  On the fast path stepQuotients hands over t * rsq(t.t) and c.c * rsq(c.c) instead
+// (one v_rsq_f32 each, 1 ulp; no Newton steps, no division): D', R'.  With u = 2^-24, a = t / |t| in real arithmetic and
+// S_j = sum_i |a_i| |V_ij| <= |V_.j|:
+//   normalize, exact: length 2.5 u (dot 1.5 u, sqrt u), quotient u -> 3.5 u per component; fast: rsq 2 u + 1.5 u, product u
+//     -> 4.5 u: the two differ by <= 8 u |a_i|;
+//   axis_j (a 3-term fma chain in both): |axis_j - axis'_j| <= (8 + 2 * 3) u S_j;  D (another chain): |D - D'| <=
+//     (14 + 6) u sum_j |c_j| S_j <= 20 u |c| |V|_F;
+//   length(c): exact sqrt(c.c) (1 + u), fast (1 + 3 u): |R - R'| <= 4 u cutoff |c| + 2 u (cutoff |c| + |r|), cutoff <= 1;
+//   |(D - R) - (D' - R')| <= u ((20 |V|_F + 6) |c| + 2 |r|)  <  E = 2^-18 ((|V|_F + 1) length(c) + |r|) = 64 u (...).
+// So |D' - R'| > E decides the reference's comparison; a lane inside the band (or NaN: st = 0, ...) that still matters
+// sends its wave through the exact sequences (coneBackfacingP).  kV = (|V|_F + 1)(1 + 2^-10), wave-uniform.
+// Operands are in the range stepQuotients' `safe` check established (radicands in [2^-96, 2^60], |r| <= 2^30), so the
+// relative bounds above hold (no denormal intermediate that matters: E >= 2^-18 * 2^-48).
+__device__ __forceinline__ lmask coneBack(const StepQuot& q, F3 cv, float r, const M33P& viewRot, float kV, lmask relevant,
+                                          uint32_t packed, const M33P& adj)
 {
     F3 axis = mulVecP(q.tn, viewRot);
     axis.z = -axis.z;
-    return mGe(dot3(cv, axis), fma_(q.cutoff, q.lenC, r));
+    const float D = dot3(cv, axis), R = fma_(q.cutoff, q.lenC, r);
+    lmask back = mGe(D, R);
+#ifndef TR_EXP_CONE_NOBAND   /* mutation test (results WRONG by design): tests/test_gpu_parity.py::test_cone_test_at_its_decision_boundary must fail without the band */
+    if (!q.coneExact) {
+        const float E = fma_(q.lenC, kV, __builtin_fabsf(r)) * 0x1p-18f;
+        const lmask certain = mAbsGt(D - R, E);
+        if (__builtin_expect((~certain & relevant) != 0ull, 0)) {
+            float unused;
+            back = __builtin_amdgcn_ballot_w64(coneBackfacingP(packed, cv, r, adj, viewRot, 1.0f, 1.0f, &unused));
+        }
+    }
+#endif
+    return back;
+}
+// |V|_F + 1 of the view rotation, inflated: coneBack's kV
+__device__ __forceinline__ float coneSlackFactor(const M43& v)
+{
+    const float f2 = dot3(v.r0, v.r0) + dot3(v.r1, v.r1) + dot3(v.r2, v.r2);
+    return (__builtin_sqrtf(f2) + 1.0f) * (1.0f + 0x1p-10f);
 }
 
 __device__ __forceinline__ M43 loadM43(const interop::Matrix& m)

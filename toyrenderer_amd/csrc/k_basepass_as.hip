@@ -67,6 +67,12 @@ constexpr uint32_t kSteps = kBatch / 2;          // two records per wave step
  * LDS per workgroup, 3 workgroups per CU) 0.511 ms, 32 (34 KB, 4 per CU) 0.482 ms, 16 (5 per CU) 0.498 ms. */
 #define TR_CULL_BATCH (TR_RING_SLOTS == 3 ? 30 : 32)
 #endif
+#ifndef TR_EARLY_PREFETCH
+/* 1: a step refills its ring slot as soon as it has read its own meshlets out of it (the top of the step) instead of
+ * behind its arithmetic: 0.85 of a step more lead for every prefetch at no cost in LDS.  Needs TR_DEFER (a lookup
+ * consumed in its own step would sit behind the prefetch in the in-order return queue). */
+#define TR_EARLY_PREFETCH 1
+#endif
 #ifndef TR_DEFER
 /* 1: the occlusion lookup of step s is consumed at the END OF STEP s + 1 (its value rides through a whole step of
  * arithmetic in a register).  Loads return in order, so a wait for the lookup of step s also waits for every ring slot
@@ -161,7 +167,9 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 //
 // LDS layout of a ring slot (2 KB per wave): [0,512) record A chunks 0-31, [512,1024) record B chunks 0-31,
 // [1024,1536) record A chunks 32-63, [1536,2048) record B chunks 32-63.
-__device__ __forceinline__ void issueMeshletLoads(char* slotLds /* wave-uniform */, const MeshletData* meshlets, uint32_t firstIdx, uint32_t lastOff, uint32_t sub16 /* 16 * sub */)
+template <bool AFTER_READS = false>
+__device__ __forceinline__ void issueMeshletLoads(char* slotLds /* wave-uniform */, const MeshletData* meshlets, uint32_t firstIdx, uint32_t lastOff, uint32_t sub16 /* 16 * sub */,
+                                                  v4f readA = v4f{ 0.f, 0.f, 0.f, 0.f }, uint32_t readB = 0u /* AFTER_READS: what this wave has just read out of the slot */)
 {
     // Every lane always loads (chunks past the record's end re-read its last chunk): the number of loads in flight never
     // depends on the data, and nothing outside the record is read.
@@ -191,11 +199,20 @@ __device__ __forceinline__ void issueMeshletLoads(char* slotLds /* wave-uniform 
 #else
 #define TR_DMA_POLICY "sc1 nt"
 #endif
-    asm volatile("s_mov_b32 m0, %2\n\t"
-                 "global_load_lds_dwordx4 %0, off " TR_DMA_POLICY "\n\t"
-                 "s_add_u32 m0, %2, 0x400\n\t"
-                 "global_load_lds_dwordx4 %1, off " TR_DMA_POLICY
-                 :: "v"(pa), "v"(pb), "s"(ldsOff) : "memory", "m0", "scc");
+    if (AFTER_READS)
+        // the slot is overwritten as soon as the loads land: the values read out of it are operands of this statement, so the
+        // compiler has waited for them (lgkmcnt) before it
+        asm volatile("s_mov_b32 m0, %2\n\t"
+                     "global_load_lds_dwordx4 %0, off " TR_DMA_POLICY "\n\t"
+                     "s_add_u32 m0, %2, 0x400\n\t"
+                     "global_load_lds_dwordx4 %1, off " TR_DMA_POLICY
+                     :: "v"(pa), "v"(pb), "s"(ldsOff), "v"(readA), "v"(readB) : "memory", "m0", "scc");
+    else
+        asm volatile("s_mov_b32 m0, %2\n\t"
+                     "global_load_lds_dwordx4 %0, off " TR_DMA_POLICY "\n\t"
+                     "s_add_u32 m0, %2, 0x400\n\t"
+                     "global_load_lds_dwordx4 %1, off " TR_DMA_POLICY
+                     :: "v"(pa), "v"(pb), "s"(ldsOff) : "memory", "m0", "scc");
 }
 #define TR_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
@@ -209,7 +226,7 @@ __device__ __forceinline__ void issueMeshletLoads(char* slotLds /* wave-uniform 
 // table is rebuilt once per frame behind the instance pass) or through the texels themselves (two texel-pair
 // loads; the late pass, which is small and follows an HZB rebuild).  Same results either way.
 #ifndef TR_CULL_WAVES_PER_EU
-#define TR_CULL_WAVES_PER_EU 5   /* waves per SIMD the register allocation aims at (<= 96 VGPRs); LDS: 5 workgroups of 31.3 KB per CU */
+#define TR_CULL_WAVES_PER_EU 4   /* waves per SIMD the register allocation aims at; LDS: 4 workgroups of 33.4 KB per CU (4, 5 and 6 per CU measured alike) */
 #endif
 template <bool FRUSTUM, bool OCCLUSION, bool CONE, bool TABLE>
 __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullKernel(MeshletCullArgs a)
@@ -223,6 +240,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
     __shared__ uint32_t s_gIdxAll[kCullWaves][kCullBatch];
     __shared__ uint32_t s_quadOff[16];                 // texel path: mip offsets
     __shared__ uint4 s_mipTab[17];                     // table path: per-mip constants indexed by exponent + 1 (cm::occTailQuad)
+    __shared__ float2 s_coneTab[256];                  // cone byte -> { axis component, cutoff } (cm::coneTableEntry)
     __shared__ uint32_t s_slowAll[kCullWaves][kSlowCap];
     __shared__ uint32_t s_slowCount[kCullWaves];
     __shared__ __attribute__((aligned(8))) uint32_t s_maskAll[kCullWaves][kCullBatch + 2];   // [0], [1]: where the deferred resolve of "the step before the first" lands
@@ -234,6 +252,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
     const cm::M43 V = cm::loadM43(a.k.m_WorldToView);
     const cm::M43P VP = cm::packM43(V);
     const cm::M33P VR = cm::rot(VP);
+    const float coneSlack = cm::coneSlackFactor(V);
     RecordInfo* s_rec = s_recAll[wave];
     uint32_t* s_gIdx = s_gIdxAll[wave];
 
@@ -245,6 +264,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
     }
     // the fast arithmetic path wants nearPlane in [2^-20, 2^20] (cm::stepQuotients)
     const bool nearInRange = a.k.m_NearPlane >= 0x1p-20f && a.k.m_NearPlane <= 0x1p20f;
+    if (CONE) s_coneTab[tid] = cm::coneTableEntry(tid);
     if (tid < kCullWaves) s_slowCount[tid] = 0;
     if (lane < 2 * kRingSlots) { s_recAll[wave][kCullBatch + lane].first = 0; s_recAll[wave][kCullBatch + lane].lastOff = 0; }
     uint32_t* s_slow = s_slowAll[wave];
@@ -355,6 +375,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
         // data: the hand-counted waits below rely on a fixed number of loads per step.
         constexpr uint32_t kLk = !OCCLUSION ? 0u : TABLE ? 1u : 2u;                  // lookup loads per step
         constexpr bool kDefer = TR_DEFER && OCCLUSION;
+        constexpr bool kEarly = TR_EARLY_PREFETCH && (kDefer || !OCCLUSION);
         // In flight across a step boundary (kDefer): the raw lookup words of step s live in lk0 / lk1[s % slots] until the
         // end of step s + 1; the rest of that step's decision rides along in ordinary registers.
         uint32_t lk0[kRingSlots], lk1[kRingSlots];
@@ -402,6 +423,9 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
             const v4f sph = *reinterpret_cast<const v4f*>(slot + ringOff);
             const uint32_t cone = *reinterpret_cast<const uint32_t*>(slot + ringOff + 16u);
             const float4 sphere = make_float4(sph.x, sph.y, sph.z, sph.w);
+            // prefetch step s + kRingSlots into this slot (past the batch: the padding entries, a harmless re-read of meshlet 0 that
+            // keeps the loads unconditional)
+            if (kEarly) issueMeshletLoads<true>(slot, a.meshlets, s_rec[r + 2 * kRingSlots].first, s_rec[r + 2 * kRingSlots].lastOff, sub16, sph, cone);
             const cm::lmask active = cm::mLeU(subEnd, ri.lastOff);                                 // :62-63 meshletIdx < numMeshlets
             cm::lmask vis = active;
             const cm::M43P W = worldOf(ri);
@@ -414,9 +438,9 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
             // every square root and division of the step (:56-62, :79, normalize :103): fast when the whole wave can
             cm::StepQuot q;
             if (OCCLUSION || CONE)
-                cm::stepQuotients<OCCLUSION, CONE>(active, cv, rad, cone, adjugateOf(ri), a.k.m_NearPlane, nearInRange, q);
+                cm::stepQuotients<OCCLUSION, CONE, true>(active, cv, rad, cone, adjugateOf(ri), a.k.m_NearPlane, nearInRange, q, s_coneTab);
             if (CONE)                                                                              // :104-108
-                vis &= ~cm::coneTail(q, cv, rad, VR);
+                vis &= ~cm::coneBack(q, cv, rad, VR, coneSlack, vis, cone, adjugateOf(ri));
             TR_STAMP(3);   // quotients + cone
             cm::lmask accept = 0ull;
             bool pair = false;
@@ -449,9 +473,8 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
                 depthSphere = os.depthSphere; pair = os.pair;
                 issueLookup(lk0[kSlot], lk1[kSlot], a.hzb.base + os.i0, a.hzb.base + os.i1, vis & ~accept);   // two texel pairs (cm::loadTexelPair)
             }
-            // prefetch step s + kRingSlots into this slot (past the batch: the padding entries, a harmless re-read of meshlet 0 that
-            // keeps the loads unconditional).  The slot's LDS reads above have returned: their values were used.
-            issueMeshletLoads(slot, a.meshlets, s_rec[r + 2 * kRingSlots].first, s_rec[r + 2 * kRingSlots].lastOff, sub16);
+            // (late prefetch: the slot's LDS reads above have returned, their values were used)
+            if (!kEarly) issueMeshletLoads(slot, a.meshlets, s_rec[r + 2 * kRingSlots].first, s_rec[r + 2 * kRingSlots].lastOff, sub16);
             TR_STAMP(4);   // lookup + prefetch issue
             if (!OCCLUSION) {
                 resolve(2u * s + 2u, vis, 0ull, false, 0.f, 0u, 0u);
@@ -461,8 +484,13 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
                 TR_STAMP(5);   // lookup wait
                 resolve(2u * s + 2u, vis, accept, pair, depthSphere, lk0[kSlot], lk1[kSlot]);
             } else {
-                // the PREVIOUS step's lookup: younger than it are its step's prefetch (2), this step's lookup (kLk) and prefetch (2)
-                if (kLk == 1) asm volatile("s_waitcnt vmcnt(5)" : "+v"(lk0[kPrev]), "+v"(lk1[kPrev]) :: "memory");
+                // the PREVIOUS step's lookup: younger than it are this step's prefetch (2) and lookup (kLk) -- and, when the
+                // prefetch is issued behind the arithmetic (!kEarly), its own step's prefetch (2).  (Step 0 with kEarly: the
+                // primed ring's youngest slot sits behind the dummy lookup too; waiting for it here is harmless.)
+                if (kEarly) {
+                    if (kLk == 1) asm volatile("s_waitcnt vmcnt(3)" : "+v"(lk0[kPrev]), "+v"(lk1[kPrev]) :: "memory");
+                    else asm volatile("s_waitcnt vmcnt(4)" : "+v"(lk0[kPrev]), "+v"(lk1[kPrev]) :: "memory");
+                } else if (kLk == 1) asm volatile("s_waitcnt vmcnt(5)" : "+v"(lk0[kPrev]), "+v"(lk1[kPrev]) :: "memory");
                 else asm volatile("s_waitcnt vmcnt(6)" : "+v"(lk0[kPrev]), "+v"(lk1[kPrev]) :: "memory");
                 TR_STAMP(5);   // lookup wait
                 resolve(2u * s, pVis, pAccept, pPair, pDepth, lk0[kPrev], lk1[kPrev]);            // the records of step s - 1 (s = 0: the dummy pair)
@@ -487,8 +515,9 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
             step(std::integral_constant<uint32_t, 1>{}, s + 1);
             if (kRingSlots == 3) step(std::integral_constant<uint32_t, 2>{}, s + 2);
         }
-        if (kDefer) {                                    // the last step's lookup
-            asm volatile("s_waitcnt vmcnt(2)" : "+v"(lk0[kRingSlots - 1u]), "+v"(lk1[kRingSlots - 1u]) :: "memory");
+        if (kDefer) {                                    // the last step's lookup: the youngest load when the prefetch goes first (kEarly), else in front of the last prefetch
+            if (kEarly) asm volatile("s_waitcnt vmcnt(0)" : "+v"(lk0[kRingSlots - 1u]), "+v"(lk1[kRingSlots - 1u]) :: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" : "+v"(lk0[kRingSlots - 1u]), "+v"(lk1[kRingSlots - 1u]) :: "memory");
             resolve(2u * nSteps, pVis, pAccept, pPair, pDepth, lk0[kRingSlots - 1u], lk1[kRingSlots - 1u]);
         }
         TR_WAIT_VMCNT(0);                               // the last (padding) prefetches: nothing may land in the ring later
