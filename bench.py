@@ -133,6 +133,8 @@ def main():
                     help="instances of the scene the CPU baseline runs on (default: all of them; C3 = 3 frames of ~0.25 s on 64 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--prime-steps", type=int, default=256,
+                    help="setup before the warm-up steps: frames run (untimed) so that the GPU is at its working clocks (0 = off)")
     ap.add_argument("--flags", type=int, default=7, help="culling flags (7 = frustum+occlusion+cone, the headline config)")
     ap.add_argument("--animate", action="store_true",
                     help="diagnostic (BASELINE configs[4]): a node hierarchy drives the instance transforms; every frame runs "
@@ -235,6 +237,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Setup, before the W warm-up steps: bring the device to its working state.  A GPU that has only uploaded a scene sits
+    # at idle clocks; with the driver's short runs (W = 5, K = 20: 16 ms in all) the timed steps then ran 4 % slower than
+    # in a 200-step run of the same binary (profiles/r3/experiments.md).  256 frames (~0.16 s), untimed, synchronised.
+    for i in range(args.prime_steps):          # a fixed count: every rank takes part in the same collectives
+        step()
+        if i % 16 == 15:
+            sync()
+    sync()
     for _ in range(max(args.warmup, 1)):      # frame 0 sees the cleared HZB; steady state afterwards
         step()
     sync()

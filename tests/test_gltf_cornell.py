@@ -165,8 +165,9 @@ def test_lod_chain_contract(tmp_path):
         scale = gltf_lite.simplify_scale(pos)
         for k in range(1, len(chain)):
             (pi, pe), (ci, ce) = chain[k - 1], chain[k]
-            assert len(ci) % 3 == 0 and 0 < len(ci) < int(len(pi) * 0.85), "kMinIndexReductionPercentage"
-            assert len(ci) > (int(len(pi) * 0.65) // 3) * 3 - 6, "stops as soon as the target index count is reached (a collapse removes two triangles)"
+            f65, f85 = float(np.float32(0.65)), float(np.float32(0.85))     # the reference's float constants (Visual.cpp:337-338)
+            assert len(ci) % 3 == 0 and 0 < len(ci) < int(len(pi) * f85), "kMinIndexReductionPercentage"
+            assert len(ci) > (int(len(pi) * f65) // 3) * 3 - 6, "stops as soon as the target index count is reached (a collapse removes two triangles)"
             assert ce >= pe * 1.5 - 1e-7 and ce > 0 and ce <= 0.1 * scale * 1.5 ** 8
             assert ci.max() < len(pos) and set(np.unique(ci)) <= set(np.unique(idx)), "a LOD draws a subset of the mesh's vertices"
             t = ci.reshape(-1, 3)
@@ -175,6 +176,15 @@ def test_lod_chain_contract(tmp_path):
             assert len(chain) == 1
         else:
             assert len(chain) >= 3
+    # KAT of the target index count (Visual.cpp:454: double(size) * 0.65f, truncated, rounded down to whole triangles): the
+    # reference's constant is a FLOAT, 0.65f = 0.64999997615..., so 60 indices ask for 36, not 39
+    asked = []
+    def spy(positions, indices, target, err):
+        asked.append((len(indices), target))
+        return indices, 0.0                                      # "no reduction": the chain stops after one request
+    for n, want in ((60, 36), (120, 75), (6000, 3897), (300, 192)):
+        gltf_lite.build_lod_chain(np.zeros((n, 3), np.float32) + np.arange(n)[:, None], np.arange(n, dtype=np.uint32), simplifier=spy)
+        assert asked[-1] == (n, want), asked[-1]
     # the simplifier alone: stops at the error bound when asked for more than the bound allows
     pos, idx = _sphere(16, 10)
     few, err = gltf_lite.simplify(pos, idx.astype(np.uint32), 30, 0.01)

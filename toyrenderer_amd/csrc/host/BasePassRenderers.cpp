@@ -1,3 +1,4 @@
+#include <atomic>
 // BasePassRenderers.cpp -- the renderers of the GPU-driven visibility path re-authored against the
 // RenderGraph / IRenderer / Graphic::AddComputePass API over the HIP back end.
 //
@@ -36,13 +37,13 @@ namespace
 struct { ShardLateFn fn = nullptr; void* user = nullptr; uint32_t presence = 0; ShardDepthFn depthFn = nullptr; void* depthUser = nullptr; } g_ShardLateExchange;
 struct ShardDepthCall { void* words = nullptr; uint64_t count = 0; };
 ShardDepthCall g_ShardDepthCall;
-std::string g_ShardDepthError;
+std::atomic<bool> g_ShardDepthFailed{ false };      // set on the queue's callback thread, read (and cleared) by the recording thread
 
 void ShardDepthTrampoline(void* user, void* hipStream)
 {
     const ShardDepthCall* c = (const ShardDepthCall*)user;
     if (g_ShardLateExchange.depthFn && g_ShardLateExchange.depthFn(g_ShardLateExchange.depthUser, c->words, c->count, hipStream) != 0)
-        g_ShardDepthError = "depth all-reduce (MAX) across ranks failed";
+        g_ShardDepthFailed.store(true, std::memory_order_release);
 }
 
 // Does SOME rank hold ids of this bucket (0 opaque, 1 alpha mask)?  Without an exchange: this rank's own list.
@@ -428,7 +429,7 @@ public:
         if (g_Scene->m_bRasterDepth && g_ShardLateExchange.fn) {
             // multi-GPU with self-rasterised depth: each rank drew only its shard's visible meshlets; the HZB every rank
             // builds must come from the whole scene's depth = element-wise MAX (reverse-Z) over the ranks.
-            if (!g_ShardDepthError.empty()) { std::string e; e.swap(g_ShardDepthError); throw nvrhi::Error(e); }
+            if (g_ShardDepthFailed.exchange(false, std::memory_order_acq_rel)) throw nvrhi::Error("depth all-reduce (MAX) across ranks failed");
             if (!g_ShardLateExchange.depthFn)
                 throw nvrhi::Error("raster depth + shard exchange needs trhost_exchange_desc.depth_allreduce_max: per-rank depth buffers would give per-rank HZBs");
             g_ShardDepthCall.words = trhip_texture_device_ptr(depthStencilBuffer->native());

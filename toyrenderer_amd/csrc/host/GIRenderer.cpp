@@ -38,6 +38,12 @@ class GIDebugRenderer : public IRenderer
         const View& view = scene.m_View;
         GIProbeVisualizationUpdateConsts k{};
         k.m_NumProbes = scene.m_NumGIProbes;
+        // :701 m_CameraOrigin = m_View.m_Eye.  This mirror takes the camera as a world-to-view matrix (Scene.h, View::SetCamera):
+        // the eye is the point that maps to the view-space origin, -t * R^T for the rigid transform [R | t] a camera is.
+        // (The culling shader does not read the field; it is filled so that the uploaded block equals the reference's.)
+        for (int j = 0; j < 3; ++j)
+            k.m_CameraOrigin[j] = -(view.m_WorldToView.m[3][0] * view.m_WorldToView.m[j][0] + view.m_WorldToView.m[3][1] * view.m_WorldToView.m[j][1] +
+                                    view.m_WorldToView.m[3][2] * view.m_WorldToView.m[j][2]);
         k.m_Frustum = CullingFrustumOf(view.m_ViewToClip);
         k.m_WorldToView = view.m_WorldToView;
         k.m_HZBDimensions = Vector2U{ scene.m_HZB->getDesc().width, scene.m_HZB->getDesc().height };

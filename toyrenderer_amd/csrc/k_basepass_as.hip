@@ -938,6 +938,7 @@ __global__ __launch_bounds__(kPackThreads) void shardPackKernel(ShardPackArgs a)
                 v = __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (v & kPackFlag) { v &= ~kPackFlag; break; }
                 if (++spins > (1u << 22)) { v = kPackPoison; break; }               // never seen; a hang would take the GPU down
+                __builtin_amdgcn_s_sleep(1);                                        // leave the issue slots to the tiles being waited for
             }
             sum += v;
             if (last) {

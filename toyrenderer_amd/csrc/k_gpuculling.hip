@@ -553,9 +553,12 @@ __global__ __launch_bounds__(kBlock) void instanceFusedKernel(InstanceCullArgs a
     const uint32_t n = threadCount<LATE>(a);
     const uint32_t numTiles = (n + kBlock - 1) / kBlock < a.numBlocks ? (n + kBlock - 1) / kBlock : a.numBlocks;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    // the counters the pass continues from: read by every workgroup before any tile can finish the pass and rewrite them
-    const uint32_t baseX = a.dispatchArgs[0];
-    const uint32_t baseLate = LATE ? 0u : *a.lateCount;
+    // The counters the pass continues from.  The LAST tile of this launch rewrites these words; every workgroup that stays
+    // takes its ticket after reading them, and the last tile closes only after all tickets are taken -- but that order
+    // rests on program order alone unless the loads are atomics the compiler may not sink below the ticket / the spin loop
+    // (relaxed, agent scope: an L2 read, no fence needed -- the values were written by an earlier launch).
+    const uint32_t baseX = __hip_atomic_load(&a.dispatchArgs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t baseLate = LATE ? 0u : __hip_atomic_load(a.lateCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // The grid covers the capacity (>= numTiles workgroups): exactly max(numTiles, 1) of them stay, each takes ONE ticket
     // = one tile.  (An empty pass is closed by workgroup 0 as "tile 0".)
     if (blockIdx.x >= (numTiles ? numTiles : 1u)) return;

@@ -369,17 +369,21 @@ class NativeShardExchange:
             if not direct and (why or rank == 0):
                 print(f"[rank {rank}] direct RCCL communicator unavailable ({why or 'another rank cannot use it'}); using torch.distributed all_gather", file=sys.stderr, flush=True)
             if direct:
-                # Step 2: all ranks construct both communicators (same order), then agree on the outcome once more.
-                try:
-                    for k in range(3 if raster_depth else 2):
+                # Step 2: all ranks construct the communicators in the same order and agree on the outcome AFTER EACH ONE: a
+                # rank whose communicator k failed must not skip the broadcast + ncclCommInitRank of communicator k + 1 while
+                # the others are inside it (mismatched collectives hang).  All ranks leave the loop together.
+                for k in range(3 if raster_depth else 2):
+                    try:
                         comm = RcclComm(dist, torch, self.world, self.rank)
                         user = (C.c_void_p * 2)(C.cast(R.ncclAllReduce if k == 2 else R.ncclAllGather, C.c_void_p).value, comm.comm.value)
                         self.comms.append(comm)
                         self._keep.append(user)
-                except Exception as e:
-                    ok = 0
-                    print(f"[rank {rank}] ncclCommInitRank failed ({e}); using torch.distributed all_gather", file=sys.stderr, flush=True)
-                direct = agree(ok)
+                    except Exception as e:
+                        ok = 0
+                        print(f"[rank {rank}] ncclCommInitRank failed ({e}); using torch.distributed all_gather", file=sys.stderr, flush=True)
+                    direct = agree(ok)
+                    if not direct:
+                        break
             self.collective = "rccl-direct" if direct else "pg"
             if direct:
                 d.slots_allgather, d.slots_user = fn_addr, C.cast(self._keep[0], C.c_void_p).value

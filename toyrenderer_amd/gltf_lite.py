@@ -332,7 +332,10 @@ def simplify(positions: np.ndarray, indices: np.ndarray, target_index_count: int
 def build_lod_chain(positions: np.ndarray, indices: np.ndarray, simplifier=simplify):
     """The LOD loop of Mesh::Initialize (Visual.cpp:326-491): returns [(indices, error)] for LOD 0..n-1, n <= 8, with
     error = accumulated relative error * simplify_scale (the value MeshLODData::m_Error carries, :345)."""
-    kTargetError, kTargetIndexCountPercentage, kMinIndexReductionPercentage = 0.1, 0.65, 0.85      # :336-338
+    # :336-338: the reference's constants are FLOATs (0.65f, 0.85f) multiplied into double(size): 60 indices -> 38.99999
+    # -> 38 -> target 36 (with the double 0.65 it would be 39 -> 39)
+    kTargetError = 0.1
+    kTargetIndexCountPercentage, kMinIndexReductionPercentage = float(np.float32(0.65)), float(np.float32(0.85))
     scale = np.float32(simplify_scale(positions))                                                 # :324
     lod_indices = np.asarray(indices, np.uint32).copy()
     lod_error = np.float32(0.0)
