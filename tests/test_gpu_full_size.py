@@ -235,8 +235,9 @@ def test_c4_full_size_animated_on_one_gpu(oracle):
     (b) a determinism digest (the same frame twice), (c) the oracle on the sub-range of the first 262 144 instances (the
     host would need 32 GB + minutes for the whole scene): their world matrices, and -- canonical order = ascending list
     order, so the sub-range's records are a PREFIX of the early pass's outputs -- records, masks and visible list of the
-    early slot bit for bit.  (The late slot's extent depends on the whole scene's late list through Q1, so it is
-    covered by the properties only.)"""
+    early slot bit for bit; (d) the INSTANCE level of the whole scene: the oracle's early and late instance passes over all
+    7.8 M instances (no meshlets needed) give the exact late list, its Q1 extent and the late slot's records -- the late
+    slot's extent depends on the whole scene's late list through Q1, which no sub-range can reproduce."""
     import hashlib
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -264,6 +265,19 @@ def test_c4_full_size_animated_on_one_gpu(oracle):
             ml[off:off + len(chunk)] = chunk
         inst = synth.gen_instances(spec, 0, K)
         hzb = oracle.HzbTexture(*view.hzb_dims)
+        # (d) whole-scene instance level
+        from toyrenderer_amd.frame import culling_frustum
+        inst_all = synth.gen_instances(spec)
+        ids_all = np.arange(n, dtype=np.uint32)
+        hzb_mid = oracle.HzbTexture(*view.hzb_dims)
+        hzb_mid.build_from_depth(depth)                            # what GenerateHZB leaves between the phases (the uploaded depth)
+        kc = np.zeros(1, I.GPUCullingPassConstants)
+        kc["m_NbInstances"] = n; kc["m_CullingFlags"] = 7; kc["m_HZBDimensions"] = view.hzb_dims
+        kc["m_Frustum"] = culling_frustum(view.viewToClip)
+        kc["m_WorldToView"] = view.worldToView; kc["m_PrevWorldToView"] = view.prevWorldToView
+        kc["m_NearPlane"] = view.nearPlane; kc["m_P00"] = view.viewToClip[0, 0]; kc["m_P11"] = view.viewToClip[1, 1]
+        kc["m_ForcedMeshLOD"] = I.kInvalidMeshLOD
+        kc["m_MeshLODTarget"] = np.float32(np.float32(2.0) / view.viewToClip[1, 1]) * np.float32(np.float32(1.0) / np.float32(view.renderH))
         digests = []
         for frame in range(2):
             nodes, _ = synth.animated_nodes(spec, frame, nodes=nodes)
@@ -274,6 +288,23 @@ def test_c4_full_size_animated_on_one_gpu(oracle):
             got_inst = r.instances(K)
             assert np.array_equal(got_inst["m_WorldMatrix"], inst["m_WorldMatrix"]), f"frame {frame}: world matrices of the sub-range"
             got = r.results()
+            # (d): early pass against the HZB the frame started with, late pass against the mid-frame HZB
+            oracle.update_instance_consts(nodes, prim_to_node, inst_all)
+            recs = np.zeros(cap, oracle.RECORD_DT)
+            args, late_n, late_ids = np.zeros(3, np.uint32), np.zeros(1, np.uint32), np.zeros(n, np.uint32)
+            valid_e = oracle.instance_cull(kc, False, inst_all, ids_all, md_full, hzb, recs, args, late_n, late_ids, 0, cap)
+            assert int(args[0]) == len(got[0]["records"]) == valid_e and int(late_n[0]) == got["lateCount"], (args, late_n, got["lateCount"])
+            assert np.array_equal(recs[:valid_e].view(np.uint32), got[0]["records"].view(np.uint32)), "early records of the whole scene"
+            late_x = int(oracle.build_late_args(int(late_n[0]))[0])
+            recs_l, args_l = np.zeros(cap, oracle.RECORD_DT), np.zeros(3, np.uint32)
+            valid_l = oracle.instance_cull(kc, True, inst_all, late_ids, md_full, hzb_mid, recs_l, args_l, late_n, late_ids, late_x, cap)
+            assert (frame == 0) == (int(late_n[0]) == 0), "frame 0 starts from the cleared HZB: nothing is deferred"
+            if got[1] is None:
+                assert valid_l == 0
+            else:
+                assert int(args_l[0]) == len(got[1]["records"]) == valid_l, (args_l, len(got[1]["records"]))
+                assert np.array_equal(recs_l[:valid_l].view(np.uint32), got[1]["records"].view(np.uint32)), "late records of the whole scene (Q1 extent)"
+            del recs, recs_l
             sub = dict(instances=inst, meshData=md, meshlets=ml, opaqueIds=np.arange(K, dtype=np.uint32), alphaMaskIds=np.zeros(0, np.uint32))
             ref = oracle.frame(sub, view.as_dict(), hzb, depth, cullingFlags=7, maxGroups=K * 4 + 1, record_capacity=K * 4 + 1, threads=16)
             G = len(ref.records[0])

@@ -298,14 +298,47 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
         const MeshletAmplificationData rec = a.records[e];
         return make_uint4(e, rec.m_InstanceConstIdx, rec.m_MeshLOD, rec.m_MeshletGroupOffset);
     };
-    uint4 entry = loadEntry(team);
-    for (uint32_t sb = team; sb < numSuper; sb += teams) {
+    // Windows are dealt round-robin: team t takes windows t, t + teams, ... for `fullRounds` rounds.  The `left` windows of
+    // the last, incomplete round would keep a fraction of the chip busy for a whole window's time while the rest idles
+    // (C3: 13.4 windows per workgroup = 14 rounds for 13.4 rounds of work); they are CUT into pieces of `stepsPer` steps
+    // instead, one piece per team, so that the last round takes left / teams of a window's time.
+#ifndef TR_NO_SPLIT_TAIL
+    const uint32_t fullRounds = numSuper / teams, left = numSuper - fullRounds * teams;
+    uint32_t piecesPer = 1u, stepsPer = kCullSteps;
+    if (left) {
+        const uint32_t k = std::min(teams / left, kCullSteps / kRingSlots);
+        if (k > 1u) {
+            stepsPer = ((kCullSteps + k - 1u) / k + kRingSlots - 1u) / kRingSlots * kRingSlots;
+            piecesPer = (kCullSteps + stepsPer - 1u) / stepsPer;
+        }
+    }
+#else
+    const uint32_t fullRounds = (numSuper + teams - 1u) / teams, left = 0u, piecesPer = 1u, stepsPer = kCullSteps;
+#endif
+    // iteration `it` of this team: window (0xFFFFFFFF = none) and the steps [s0, s1) of it
+    auto windowOf = [&](uint32_t it, uint32_t& s0, uint32_t& s1) -> uint32_t {
+        s0 = 0u; s1 = kCullSteps;
+        if (it < fullRounds) { const uint64_t w = (uint64_t)it * teams + team; return w < numSuper ? (uint32_t)w : 0xFFFFFFFFu; }
+        if (it == fullRounds && left && team < left * piecesPer) {
+            s0 = (team % piecesPer) * stepsPer;
+            s1 = std::min(s0 + stepsPer, kCullSteps);
+            return fullRounds * teams + team / piecesPer;
+        }
+        return 0xFFFFFFFFu;
+    };
+    uint32_t s0 = 0, s1 = kCullSteps, sbNext, s0n, s1n;
+    uint32_t sb = windowOf(0u, s0, s1);
+    uint4 entry = loadEntry(sb);
+    for (uint32_t it = 0; sb != 0xFFFFFFFFu; ++it, sb = sbNext, s0 = s0n, s1 = s1n) {
+        sbNext = windowOf(it + 1u, s0n, s1n);
         const uint32_t sbBase = sb * superSize;
         if (sbBase + 2 * waveInTeam >= G) break;                                     // nothing left for this wave
-        // steps of this window that still hold records for this wave (wave-uniform), rounded up to even
+        // steps of this window that still hold records for this wave (wave-uniform), rounded up to whole trips round the ring
         const uint32_t remaining = G - sbBase - 2 * waveInTeam;
         uint32_t nSteps = (remaining + 2 * teamWaves - 1) / (2 * teamWaves);
-        nSteps = nSteps < kCullSteps ? (nSteps + kRingSlots - 1u) / kRingSlots * kRingSlots : kCullSteps;   // whole trips round the ring
+        nSteps = nSteps < kCullSteps ? (nSteps + kRingSlots - 1u) / kRingSlots * kRingSlots : kCullSteps;
+        nSteps = nSteps < s1 ? nSteps : s1;                                          // this team's piece of the window: steps [s0, nSteps)
+        if (s0 >= nSteps) break;                                                     // (only a piece of the partial last window can be empty: the last iteration)
         TR_STAMP(0);   // between batches
         // ---- prologue: lane l resolves its record (basepass.hlsl:52-58) through the instance cull cache: ONE
         //      level of dependent loads here -- the entry itself was fetched while the previous batch ran ------
@@ -321,11 +354,15 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
 #pragma unroll
             for (int i = 0; i < 3; ++i) ri.adjz[i] = 0.f;
             const uint4 cur = entry;
-            entry = loadEntry(sb + teams);                                           // next batch's entry: in flight during this batch
-            const uint32_t g = cur.x < G ? cur.x : 0xFFFFFFFFu;
+            entry = loadEntry(sbNext);                                               // next batch's entry: in flight during this batch
+            const uint32_t g = cur.x < G && (lane >> 1) >= s0 && (lane >> 1) < nSteps ? cur.x : 0xFFFFFFFFu;
             if (lane < kCullBatch) s_gIdx[lane] = g;
             if (g < G) {
+#ifdef TR_EXP_INST0     /* experiment, results WRONG: every record reads instance block 0 (what the scattered 64-byte reads cost) */
+                const uint32_t cid = 0u;
+#else
                 const uint32_t cid = cur.y < a.numInstances ? cur.y : 0u;            // never read outside the cache
+#endif
                 const float4* wr = a.cache.world + 4ull * cid;                       // one 64-byte block: world rows + max scale
                 const float4 q0 = wr[0], q1 = wr[1], q2 = wr[2], q3 = wr[3];
                 const cm::F3 r0 = { q0.x, q0.y, q0.z }, r1 = { q0.w, q1.x, q1.y }, r2 = { q1.z, q1.w, q2.x };
@@ -503,14 +540,14 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
         // lands in s_mask[0], [1].
 #pragma unroll
         for (uint32_t k = 0; k + 1 < kRingSlots; ++k)
-            issueMeshletLoads(ring + 2048u * k, a.meshlets, s_rec[2 * k + half].first, s_rec[2 * k + half].lastOff, sub16);
+            issueMeshletLoads(ring + 2048u * k, a.meshlets, s_rec[2 * (s0 + k) + half].first, s_rec[2 * (s0 + k) + half].lastOff, sub16);
         if (kDefer) {
             const void* p = TABLE ? (const void*)a.quad.base : (const void*)a.hzb.base;
             issueLookup(lk0[kRingSlots - 1u], lk1[kRingSlots - 1u], p, p, 0ull);
         }
-        issueMeshletLoads(ring + 2048u * (kRingSlots - 1u), a.meshlets, s_rec[2 * (kRingSlots - 1u) + half].first, s_rec[2 * (kRingSlots - 1u) + half].lastOff, sub16);
+        issueMeshletLoads(ring + 2048u * (kRingSlots - 1u), a.meshlets, s_rec[2 * (s0 + kRingSlots - 1u) + half].first, s_rec[2 * (s0 + kRingSlots - 1u) + half].lastOff, sub16);
 #pragma unroll 1
-        for (uint32_t s = 0; s < nSteps; s += kRingSlots) {
+        for (uint32_t s = s0; s < nSteps; s += kRingSlots) {
             step(std::integral_constant<uint32_t, 0>{}, s);
             step(std::integral_constant<uint32_t, 1>{}, s + 1);
             if (kRingSlots == 3) step(std::integral_constant<uint32_t, 2>{}, s + 2);
@@ -559,7 +596,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
                         else atomicAnd(&s_mask[r + 2u], ~(1u << m));
                     }
                 } else {                                                             // list overflow: redo the whole batch exactly
-                    for (uint32_t s = 0; s < nSteps; ++s) {
+                    for (uint32_t s = s0; s < nSteps; ++s) {
                         const uint32_t r = 2 * s + half;
                         const unsigned long long ballot = __ballot(exactVisible(r, sub));
                         if (sub == 0) s_mask[r + 2u] = half ? (uint32_t)(ballot >> 32) : (uint32_t)ballot;
@@ -573,7 +610,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
         // ---- the batch's 64 masks leave in one store (lane l: record l of the batch) ----------------------------
         {
             const uint32_t g = lane < kCullBatch ? s_gIdx[lane] : 0xFFFFFFFFu;
-            if (g < G && (lane >> 1) < nSteps) a.visMask[g] = s_mask[(lane < kCullBatch ? lane : 0u) + 2u];
+            if (g < G) a.visMask[g] = s_mask[(lane < kCullBatch ? lane : 0u) + 2u];     // (g is none outside this team's piece of the window)
         }
     }
 #ifdef TR_STAMPS
