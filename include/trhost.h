@@ -140,6 +140,12 @@ typedef struct trhost_exchange_desc {
      * submitted instance, so the number of id-list entries of the largest shard bounds it.  0: slot_groups (always
      * enough).  Slot size = 16 + 4 * slot_runs + slot_groups words. */
     uint32_t slot_runs;
+    /* Q2 (gpuculling.hlsl:64-74) made global.  > 0: the group capacity (max_groups) of the single-GPU run this exchange
+     * reproduces; every rank must run its passes with that same capacity.  The unpack then cuts the rank-major
+     * concatenation in front of the first instance the single-GPU pass would drop (its position follows from the ranks'
+     * dispatch counters in the slot headers; protocol: toyrenderer_amd/gather.py) and reports {sum of the counters, 1, 1,
+     * validRecords}.  0: a rank that drops groups only raises status bit 8 in the whole-scene arguments. */
+    uint32_t global_group_capacity;
 } trhost_exchange_desc;
 int  trhost_exchange_create(const trhost_exchange_desc* desc);   /* also installs the in-frame late-count hook      */
 int  trhost_exchange_run(void);                                  /* after trhost_frame: pack, gather, unpack (async) */

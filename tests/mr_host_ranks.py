@@ -6,6 +6,9 @@ collectives), checked against the oracle's single-GPU frame of the whole scene. 
 uneven: the opaque ids are spread over ranks 0..N-2 and ALL alpha-mask ids sit on the last rank, so some ranks hold no
         alpha-mask list and one holds no opaque list: every rank must still post the same in-frame late-count collectives
         (BasePassRenderers.cpp GPUCulling, `list_presence_mask`).
+q2:     every rank runs with the group capacity of the single-GPU run (far below what the scene needs); the exchange is given
+        that capacity (`global_group_cap`) and must deliver exactly the 1-rank oracle frame's valid prefix and
+        {X, 1, 1, validRecords}, wherever the first dropped instance lies (Q2 made global, gather.py).
 raster: every rank rasterises the depth of its own shard's visible meshlets; the depth buffers are MAX-combined across
         ranks before each HZB build (`depth_allreduce_max`), so lists, depth and HZB equal the single-GPU frame."""
 import os
@@ -74,6 +77,40 @@ def main():
             ex.close()
         finally:
             r.shutdown()
+    elif mode == "q2":
+        render = (640, 360)
+        spec = synth.SceneSpec(num_meshes=24, num_instances=900, meshlets_lod0=70, jitter_meshlets=True, max_lods=4, seed=777)
+        scene = synth.make_scene(spec)
+        view = synth.make_view(eye=(0.5, 0.2, 1.0), yaw=0.03, prev_eye=(0.0, 0.0, 0.0), prev_yaw=0.0, render=render)
+        d_prev = synth.gen_depth(view, num_occluders=60, seed=11, scale=3.0)
+        d_cur = synth.gen_depth(view, num_occluders=40, seed=12, scale=3.0)
+        op = scene.opaqueIds
+        a, b = shard_range(len(op), rank, world)
+        h0 = oracle.HzbTexture(*view.hzb_dims); h0.build_from_depth(d_prev)
+        free = oracle.frame(scene.as_oracle(), view.as_dict(), h0, d_cur, cullingFlags=7, maxGroups=1 << 20, record_capacity=1 << 16)
+        GE = int(free.dispatchArgs[0][0])
+        assert GE > 300
+        for cap in (GE // (2 * world) + 1, GE // 2, GE - 3):          # the first dropped instance on rank 0, in the middle, on the last rank
+            hzb = oracle.HzbTexture(*view.hzb_dims)
+            hzb.build_from_depth(d_prev)
+            r = host.Renderer(render=render, max_groups=cap)
+            try:
+                r.load_scene(scene.instances, scene.meshData, scene.meshlets, op[a:b], np.zeros(0, np.uint32))
+                r.set_culling(7)
+                r.upload_hzb(hzb.texels, hzb.offsets)
+                r.upload_depth(d_cur)
+                ex = NativeShardExchange(r, dist, world, rank, slot_groups=2 * cap, pass_slots=(0, 1), group_capacity=2 * cap * world,     # a slot holds the early AND the late pass
+                                         stage_through_host=True, slot_runs=len(op), global_group_cap=cap)
+                for f in range(2):
+                    r.set_camera(view)
+                    r.frame()
+                    ex.run()
+                    ref = oracle.frame(scene.as_oracle(), view.as_dict(), hzb, d_cur, cullingFlags=7, maxGroups=cap, record_capacity=cap)
+                    assert int(ref.validRecords[0]) < int(ref.dispatchArgs[0][0]), "the capacity must bite"
+                    check_slots(ex, ref, f"cap {cap} frame {f}")
+                ex.close()
+            finally:
+                r.shutdown()
     elif mode == "raster":
         from scene_gen import write_city_gltf
         from toyrenderer_amd import gltf_lite

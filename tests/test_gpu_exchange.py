@@ -82,7 +82,7 @@ def _same_used_words(got, ref, S, R):
             and np.all(got[H + 4 * runs:H + 4 * R] == 0xDEADBEEF) and np.all(got[H + 4 * R + groups:] == 0xDEADBEEF))
 
 
-def _unpack(dev, recv, world, slot_groups, pass_slots, group_cap, list_cap, slot_runs=None):
+def _unpack(dev, recv, world, slot_groups, pass_slots, group_cap, list_cap, slot_runs=None, global_cap=None):
     from toyrenderer_amd import rhi
     R = slot_groups if slot_runs is None else slot_runs
     rb = dev.buffer_from(np.asarray(recv, np.uint32), "recv")
@@ -95,7 +95,8 @@ def _unpack(dev, recv, world, slot_groups, pass_slots, group_cap, list_cap, slot
         binds += [rhi.UAV(4 * s, o["records"]), rhi.UAV(4 * s + 1, o["masks"]), rhi.UAV(4 * s + 2, o["list"]), rhi.UAV(4 * s + 3, o["args"])]
     cl = dev.create_command_list()
     cl.open()
-    cl.dispatch("visibility_CS_UnpackShards", binds, (1, 1, 1), push=np.array([world, slot_groups, R], np.uint32))
+    push = [world, slot_groups, R] + ([int(global_cap)] if global_cap else [])          # the 4th word is optional (Q2 made global)
+    cl.dispatch("visibility_CS_UnpackShards", binds, (1, 1, 1), push=np.array(push, np.uint32))
     cl.close()
     res = {}
     for _ in range(2):                                  # a recorded list is re-executed every other frame
@@ -103,7 +104,7 @@ def _unpack(dev, recv, world, slot_groups, pass_slots, group_cap, list_cap, slot
     dev.wait_idle()
     for s in pass_slots:
         a = outs[s]["args"].download(np.uint32, 8)
-        G, V = int(a[0]), int(a[4])
+        G, V = min(int(a[0]), int(a[3])), int(a[4])
         res[s] = dict(args=a, G=G, V=V, status=int(a[7]), records=outs[s]["records"].download(np.uint32, 3 * min(G, group_cap)).reshape(-1, 3),
                       masks=outs[s]["masks"].download(np.uint32, min(G, group_cap)), list=outs[s]["list"].download(np.uint32, min(V, list_cap)))
     cl.release()
@@ -175,6 +176,54 @@ def test_pack_unpack_kernels_equal_numpy_protocol(dev, world, pass_slots, max_gr
         assert np.array_equal(got[s]["records"], ref[s]["records"])
         assert np.array_equal(got[s]["masks"], ref[s]["masks"])
         assert np.array_equal(got[s]["list"], ref[s]["list"])
+
+
+@pytest.mark.parametrize("world", [2, 5, 16])
+def test_unpack_makes_the_group_capacity_drop_global(dev, world):
+    """Q2 made global (gather.py): ranks whose dispatch counters counted more groups than they sent, capacities that put
+    the first dropped instance on every rank in turn, on a rank's own dropped instance, nowhere: HIP unpack == numpy
+    protocol word for word ({sum of the counters, 1, 1, validRecords}, records, masks, list)."""
+    rng = np.random.default_rng(70 + world)
+    pass_slots, G = (0, 1), 600
+    S = 2 * G + 3
+    locals_ = []
+    for p in range(world):
+        loc = {}
+        for s in pass_slots:
+            g = int(rng.integers(0, G + 1)) if p != 1 else 0
+            rec = _run_records(rng, g)
+            m = rng.integers(0, 2 ** 32, g, dtype=np.uint64).astype(np.uint32)
+            counted = g + (int(rng.integers(1, 30)) if rng.random() < 0.4 else 0)                   # the rank dropped groups itself
+            loc[s] = (rec, m, 0, counted)
+        locals_.append(loc)
+    r0 = locals_[0][0]
+    locals_[0][0] = (r0[0], r0[1], 0, len(r0[0]) + 7)                                               # at least one rank dropped groups
+    state, _ = _pack_state(dev, S)
+    slots = []
+    for loc in locals_:
+        got = _pack(dev, loc, S, state=state)
+        ref = pack_shard_np(loc, S)
+        assert np.array_equal(got[:gather.HEADER_WORDS], ref[:gather.HEADER_WORDS])
+        slots.append(got)
+    state.release()
+    recv = np.concatenate(slots)
+    total = [sum(loc[s][3] for loc in locals_) for s in pass_slots]
+    caps = sorted(set([1, 2, 3, min(total) // 2, min(total) - 1, min(total), max(total), max(total) + 1, max(total) + 100]
+                      + [int(x) for x in rng.integers(1, max(total) + 2, 12)]))
+    for cap in caps:
+        if cap < 1:
+            continue
+        got = _unpack(dev, recv, world, S, pass_slots, world * S, 32 * world * S, global_cap=cap)
+        ref = unpack_shards_np(recv, world, S, pass_slots, world * S, global_cap=cap)
+        for i, s in enumerate(pass_slots):
+            assert got[s]["status"] == 0 and ref[s]["status"] == 0
+            assert list(got[s]["args"][:7]) == [ref[s]["X"], 1, 1, ref[s]["G"], ref[s]["V"], 1, 1], (cap, s, got[s]["args"], ref[s]["X"], ref[s]["G"])
+            assert ref[s]["X"] == total[i] and ref[s]["G"] <= min(cap, total[i])
+            assert np.array_equal(got[s]["records"], ref[s]["records"]) and np.array_equal(got[s]["masks"], ref[s]["masks"])
+            assert np.array_equal(got[s]["list"], ref[s]["list"])
+    # without the capacity the drop is flagged (status bit 8), as before
+    got = _unpack(dev, recv, world, S, pass_slots, world * S, 32 * world * S)
+    assert all(got[s]["status"] & 8 for s in pass_slots)
 
 
 def test_overflow_is_flagged_not_silent(dev):

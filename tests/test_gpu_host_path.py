@@ -321,3 +321,11 @@ def test_randomised_sweep_through_the_host_mirror(oracle, block):
                         assert np.array_equal(r.download_hzb(), hzb.texels), "HZB chain"
         except AssertionError as e:
             raise AssertionError(f"case {case}: {spec} render={render} flags={flags} forced={forced} freeze={freeze} cap={cap}: {e}") from e
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_group_capacity_drop_is_global_with_real_ranks(world, tmp_path):
+    """Q2 (gpuculling.hlsl:64-74) under sharding through the C++ host path: real ranks (sharing the one GPU, gloo), every
+    rank at the single-GPU group capacity, which bites; the exchange (`global_group_cap`) delivers the 1-rank oracle frame."""
+    out = _run_ranks(world, "q2", tmp_path)
+    assert out.count("q2: ok") == world

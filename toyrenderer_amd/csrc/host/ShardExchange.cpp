@@ -97,7 +97,7 @@ void recordUnpack(Exchange& x, int b)
             binds.push_back(bind(TRHIP_BIND_STRUCTURED_UAV, 4 * s + 2, x.list[s]));
             binds.push_back(bind(TRHIP_BIND_STRUCTURED_UAV, 4 * s + 3, x.args[s]));
         }
-    const uint32_t push[3] = { x.desc.world, x.desc.slot_groups, x.slotRuns };
+    const uint32_t push[4] = { x.desc.world, x.desc.slot_groups, x.slotRuns, x.desc.global_group_capacity };
     require(trhip_cmd_open(x.unpackList[b]), "exchange: open unpack list");
     require(trhip_cmd_dispatch(x.unpackList[b], "visibility_CS_UnpackShards", binds.data(), (uint32_t)binds.size(), push, sizeof push, 1, 1, 1),
             "exchange: record visibility_CS_UnpackShards");

@@ -859,7 +859,8 @@ __global__ __launch_bounds__(kCompactThreads) void visCompactKernel(MeshletCullA
 // count/scan/expand kernels the single-GPU path uses: the result is bit-identical to a single-GPU frame.
 //
 // Shard slot (u32 words), S = slotGroups, R = slotRuns:
-//   [0..15]         header: {G_s, V_s} for pass slot s = 0..3 at words 2s, 2s+1; word 8 = overflow flag (groups > S or
+//   [0..15]         header: {G_s, X_s} for pass slot s = 0..3 at words 2s, 2s+1 (groups sent; groups the dispatch counter
+//                   counted, dropped ones included: Q2 made global, gather.py); word 8 = overflow flag (groups > S or
 //                   runs > R), word 9 = the rank dropped groups at its record capacity (Q2), words 10..13 = runs of
 //                   pass slots 0..s (cumulative end of pass slot s in the run array)
 //   [16, 16+4R)     run entries of pass slot 0, then 1, ... back to back (4 words each)
@@ -1030,7 +1031,7 @@ __global__ __launch_bounds__(kPackThreads) void shardPackKernel(ShardPackArgs a)
 #pragma unroll
             for (uint32_t q = 0; q < kMaxPassSlots; ++q) {
                 if (tid == 2 * q) v = G[q];
-                if (tid == 2 * q + 1) v = a.drawArgs[q] ? a.drawArgs[q][0] : 0u;
+                if (tid == 2 * q + 1) v = a.dispatchArgs[q] ? a.dispatchArgs[q][0] : 0u;   // the counter: dropped groups included (Q2)
                 if (tid == 10 + q) v = poisoned ? 0xFFFFFFFFu : (uint32_t)end[q];
             }
             if (tid == 8) v = (overflow || allRuns > a.slotRuns || poisoned) ? 1u : 0u;
@@ -1054,6 +1055,7 @@ struct ShardUnpackArgs
     uint32_t* masks[kMaxPassSlots];
     uint32_t* args[kMaxPassSlots];         // 8 words: {G,1,1,G} dispatch args, {V,1,1} draw args, status
     uint32_t capacity[kMaxPassSlots];      // groups
+    uint32_t globalCap;                    // > 0: Q2 made global -- the single-GPU run's group capacity (gather.py)
 };
 
 // Rank-major rebuild.  Segment k = (rank p, pass slot s); every block derives the segment table from the slot headers
@@ -1078,9 +1080,11 @@ __global__ __launch_bounds__(256) void shardUnpackKernel(ShardUnpackArgs a)
     if (tid == 0) {
         uint32_t status = 0, maskRun = 0, runRun = 0, k = 0;
         uint32_t off[kMaxPassSlots] = {};
+        unsigned long long counted[kMaxPassSlots] = {};                            // Q2 made global: groups counted by the lower ranks
+        bool cutDone[kMaxPassSlots] = {};
         for (uint32_t p = 0; p < a.world; ++p) {
             if (a.recv[(uint64_t)p * slotWords + 8u]) status |= 1u;                // that rank's slot overflowed
-            if (a.recv[(uint64_t)p * slotWords + 9u]) status |= 8u;                // that rank dropped groups (Q2)
+            if (a.recv[(uint64_t)p * slotWords + 9u] && !a.globalCap) status |= 8u; // that rank dropped groups (Q2) and nobody resolves it
             uint32_t inSlot = 0, runBegin = 0;
             bool bad = false;
             for (uint32_t s = 0; s < kMaxPassSlots; ++s) {
@@ -1092,6 +1096,26 @@ __global__ __launch_bounds__(256) void shardUnpackKernel(ShardUnpackArgs a)
                 uint32_t runEnd = s_E[p][s];
                 if (inSlot > a.slotGroups || inSlot < sentG || runEnd < runBegin || runEnd > a.slotRuns) bad = true;   // corrupt header: copy nothing
                 if (bad) { status |= 4u; g = 0; runEnd = runBegin; }
+                if (a.globalCap && a.records[s] && !bad) {
+                    // the first instance the single-GPU pass drops lies on the first rank whose counted groups reach the
+                    // capacity: the run containing local record cap - before - 1 (gather.py); behind it nothing counts
+                    const unsigned long long x = a.recv[(uint64_t)p * slotWords + 2u * s + 1u];
+                    if (cutDone[s]) g = 0;
+                    else if (counted[s] + x >= a.globalCap) {
+                        cutDone[s] = true;
+                        const unsigned long long j = a.globalCap - counted[s] - 1ull;
+                        if (j < g) {
+                            const uint32_t* run = a.recv + (uint64_t)p * slotWords + kSlotHeaderWords + 4ull * runBegin;
+                            uint32_t lo = 0, hi = runEnd - runBegin;                    // last run with first record <= j (run 0 starts at 0)
+                            while (hi - lo > 1u) {
+                                const uint32_t mid = (lo + hi) >> 1;
+                                if (run[4ull * mid + 3u] <= j) lo = mid; else hi = mid;
+                            }
+                            g = hi > lo ? run[4ull * lo + 3u] : 0u;
+                        }
+                    }
+                    counted[s] += x;
+                }
                 uint32_t runs = a.records[s] ? runEnd - runBegin : 0u;
                 if (off[s] + g > a.capacity[s]) { g = a.capacity[s] - off[s]; status |= 2u; }
                 const uint32_t base = p * slotWords + kSlotHeaderWords;            // < 2^32 words (checked on the host)
@@ -1107,7 +1131,9 @@ __global__ __launch_bounds__(256) void shardUnpackKernel(ShardUnpackArgs a)
         if (blockIdx.x == 0)
             for (uint32_t s = 0; s < kMaxPassSlots; ++s)
                 if (a.args[s]) {
-                    a.args[s][0] = off[s]; a.args[s][1] = 1; a.args[s][2] = 1; a.args[s][3] = off[s];
+                    // {X, 1, 1, validRecords}: with the global capacity X is the sum of the ranks' counters, as on one GPU
+                    const unsigned long long X = a.globalCap ? counted[s] : off[s];
+                    a.args[s][0] = X > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)X; a.args[s][1] = 1; a.args[s][2] = 1; a.args[s][3] = off[s];
                     a.args[s][7] = status;
                 }
     }
@@ -1404,12 +1430,13 @@ int recordUnpackShards(trhip::DispatchCtx& ctx)
 {
     const uint32_t* push = (const uint32_t*)ctx.constants(0, 12);
     trhip_buffer_t* recv = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 0);
-    TRHIP_REQUIRE(push && recv, "%s: needs push constants {world, slotGroups, slotRuns} and SRV t0 (gathered slots)", ctx.shaderName);
+    TRHIP_REQUIRE(push && recv, "%s: needs push constants {world, slotGroups, slotRuns[, globalGroupCapacity]} and SRV t0 (gathered slots)", ctx.shaderName);
     ShardUnpackArgs a;
     memset(&a, 0, sizeof a);
     a.world = push[0];
     a.slotGroups = push[1];
     a.slotRuns = push[2];
+    if (const uint32_t* push4 = (const uint32_t*)ctx.constants(0, 16)) a.globalCap = push4[3];   // optional 4th word
     TRHIP_REQUIRE(a.world >= 1 && a.world <= kMaxRanks, "%s: world size %u outside [1, %u]", ctx.shaderName, a.world, kMaxRanks);
     const uint64_t words = (uint64_t)a.world * (kSlotHeaderWords + 4ull * a.slotRuns + a.slotGroups);
     TRHIP_REQUIRE(words < (1ull << 32), "%s: %u slots of %u groups / %u runs exceed 2^32 words", ctx.shaderName, a.world, a.slotGroups, a.slotRuns);

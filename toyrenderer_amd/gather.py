@@ -12,7 +12,8 @@ What crosses xGMI is the compact form of a rank's pass slots, in one fixed-capac
 On the 100 M-meshlet config (4 groups per instance) that is 8 bytes per group: 25 MB per frame instead of the 143 MB of
 the visible lists.
 
-    words [0, 16)             header: {G_s, V_s} of pass slot s at words 2s, 2s+1; word 8 = overflow flag (groups > S or
+    words [0, 16)             header: {G_s, X_s} of pass slot s at words 2s, 2s+1 (groups sent = the rank's valid records; groups
+                              its dispatch counter counted, which includes the groups of instances dropped at the capacity); word 8 = overflow flag (groups > S or
                               runs > R); word 9 = groups dropped (Q2); words 10..13 = cumulative run count after pass slot s
     words [16, 16+4R)         run entries of pass slot 0, then 1, ... back to back (R = slot_runs)
     words [16+4R, 16+4R+S)    lane masks in the same order (S = slot_groups)
@@ -32,8 +33,17 @@ ranks} for the late dispatch.  The late count is final right after the EARLY ins
 exchange is posted there, on an auxiliary stream, and has the whole early meshlet cull and HZB build to
 complete; the compute stream only waits for its event before the late instance cull (`late_exchange`,
 hooked into the frame through trhost_set_shard_late_exchange / FrameDriver(shard_late=...)).
-Group-capacity overflow (the reference's 65 535-group cap, Q2) is NOT made global: a sharded run equals
-the single-GPU run only if no rank drops groups; a rank that does raises STATUS_GROUPS_DROPPED.
+Group-capacity overflow (the reference's 65 535-group cap, Q2, gpuculling.hlsl:64-74) is made GLOBAL by the unpack when the
+exchange is given `global_group_cap` = the capacity of the single-GPU run it reproduces (every rank runs its passes with
+that same maxGroups): in rank-major order rank p's groups start at B_p = sum of the lower ranks' COUNTED groups X_q (the
+counter advances for dropped instances too).  The first instance the single-GPU pass drops is the first whose run ends at
+or beyond the capacity, i.e. the run that contains global record index cap - 1; it lies on the first rank with B_p + X_p >=
+cap, starts at that rank's record `first` of the run entry containing local index cap - B_p - 1 (or is the instance the
+rank dropped itself), and everything behind it is undefined in the reference (stale buffer contents; this build's
+convention: not part of the result).  So ranks below contribute all their groups, that rank its first `first` groups,
+ranks above nothing; the whole-scene arguments are {sum X_p, 1, 1, validRecords}.  No collective inside the frame: the
+ranks' own passes run on supersets, the unpack trims.  Without `global_group_cap` a rank that drops groups raises
+STATUS_GROUPS_DROPPED (results() raises).
 torch.distributed is plumbing here: it launches the ranks and carries the 128-byte RCCL unique ids; the collectives
 themselves are direct ncclAllGather calls on this module's own communicators and streams (`RcclComm`).
 """
@@ -98,7 +108,8 @@ class ShardExchange:
     tests/exchange_ref.py); on the GPU the same sequence is driven natively (NativeShardExchange, ShardExchange.cpp)."""
 
     def __init__(self, dist, torch, world: int, rank: int, slot_groups: int, pass_slots=(0, 1),
-                 group_capacity: int | None = None, list_capacity: int | None = None, device="cpu", slot_runs: int | None = None):
+                 group_capacity: int | None = None, list_capacity: int | None = None, device="cpu", slot_runs: int | None = None,
+                 global_group_cap: int | None = None):
         assert 1 <= len(pass_slots) <= MAX_PASS_SLOTS and all(0 <= s < MAX_PASS_SLOTS for s in pass_slots)
         self.dist, self.torch, self.world, self.rank = dist, torch, int(world), int(rank)
         self.slot_groups = int(slot_groups)
@@ -110,6 +121,10 @@ class ShardExchange:
         assert self.group_capacity <= 1 << 27, "more than 2^27 groups cannot be encoded as (g << 5) | lane"
         self.list_capacity = int(list_capacity if list_capacity is not None else 32 * self.group_capacity)
         self.device = device
+        # Q2 made global: the group capacity (maxGroups) of the single-GPU run this exchange reproduces -- every rank runs its
+        # passes with the same value; the unpack cuts the rank-major concatenation in front of the first instance that run
+        # would drop.  None: a rank that drops groups makes results() raise (STATUS_GROUPS_DROPPED).
+        self.global_group_cap = int(global_group_cap) if global_group_cap else None
         i32 = torch.int32
         self.send = [torch.zeros(self.slot_words, dtype=i32, device=device) for _ in range(2)]
         self.recv = [torch.zeros(self.world * self.slot_words, dtype=i32, device=device) for _ in range(2)]
@@ -165,7 +180,7 @@ class ShardExchange:
         self.wait()
         o = self.out[pass_slot]
         args = o["args"].cpu().numpy().view(np.uint32)
-        G, V, status = int(args[0]), int(args[4]), int(args[7])
+        G, V, status = min(int(args[0]), int(args[3])), int(args[4]), int(args[7])     # {X, 1, 1, validRecords}: X counts dropped groups too (Q2)
         if status:
             raise RuntimeError(f"shard exchange failed (status {status}): "
                                + ("a rank's groups exceed slot_groups; " if status & STATUS_SLOT_OVERFLOW else "")
@@ -254,7 +269,7 @@ class NativeShardExchange:
     def __init__(self, renderer, dist, world: int, rank: int, slot_groups: int, pass_slots=(0, 1),
                  group_capacity: int | None = None, list_capacity: int | None = None, overlap: bool = True,
                  stage_through_host: bool = False, loopback: bool = False, raster_depth: bool = False,
-                 slot_runs: int | None = None):
+                 slot_runs: int | None = None, global_group_cap: int | None = None):
         """slot_runs: run entries a shard slot holds (shard_run_capacity of the largest shard; None = slot_groups).
         raster_depth: the frames rasterise their own depth (trhost_set_raster_depth): adds the cross-rank MAX of the
         depth buffer before every HZB build (one more communicator / process group)."""
@@ -273,6 +288,7 @@ class NativeShardExchange:
         d.world, d.rank, d.slot_groups, d.group_capacity = self.world, self.rank, int(slot_groups), self.group_capacity
         d.list_capacity, d.overlap = self.list_capacity, int(bool(overlap))
         d.slot_runs = int(slot_groups if slot_runs is None else slot_runs)
+        d.global_group_capacity = int(global_group_cap or 0)          # Q2 made global (module docstring)
         d.pass_slot_mask = sum(1 << s for s in self.pass_slots)
         # which id lists exist on SOME rank: every rank posts the in-frame late-count collective of exactly those buckets
         n_op, n_am = C.c_uint32(), C.c_uint32()
@@ -450,7 +466,7 @@ class NativeShardExchange:
         h = [C.c_void_p() for _ in range(4)]
         self.host._check(self._L.trhost_exchange_outputs(int(pass_slot), *[C.byref(x) for x in h]))
         args = self.host._download(h[3].value, np.uint32, 8)
-        G, V, status = int(args[0]), int(args[4]), int(args[7])
+        G, V, status = min(int(args[0]), int(args[3])), int(args[4]), int(args[7])     # {X, 1, 1, validRecords}: X counts dropped groups too (Q2)
         if status:
             raise RuntimeError(f"shard exchange failed (status {status}): "
                                + ("a rank's groups exceed slot_groups; " if status & STATUS_SLOT_OVERFLOW else "")

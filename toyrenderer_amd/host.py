@@ -34,7 +34,7 @@ class ExchangeDesc(C.Structure):
                 ("list_capacity", C.c_uint64), ("pass_slot_mask", C.c_uint32), ("overlap", C.c_int),
                 ("slots_allgather", C.c_void_p), ("slots_user", C.c_void_p), ("late_allgather", C.c_void_p), ("late_user", C.c_void_p),
                 ("list_presence_mask", C.c_uint32), ("depth_allreduce_max", C.c_void_p), ("depth_user", C.c_void_p),
-                ("slot_runs", C.c_uint32)]
+                ("slot_runs", C.c_uint32), ("global_group_capacity", C.c_uint32)]
 
 
 DEPTH_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)   # trhost_exchange_desc.depth_allreduce_max
