@@ -333,10 +333,13 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, committed summary):
         # only valid for the exact workload it was measured on
+        # The committed PMC figure belongs to ONE build of the kernel: it carries the hash of the kernel's sources + build flags
+        # (kernel_source_sha16) and is reported only while they are unchanged; null otherwise.
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r2", "traffic.json")))
-            if tj["config"] == args.config and tj["culling_flags"] == args.flags and tj["kernel"] == DOMINANT and world == 1:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r3", "traffic.json")))
+            if (tj["config"] == args.config and tj["culling_flags"] == args.flags and tj["kernel"] == DOMINANT and world == 1
+                    and tj.get("kernel_source_sha16") == kernel_source_sha16()):
                 traffic = int(tj["hbm_bytes_per_launch"])
         except (OSError, KeyError, ValueError):
             pass
@@ -420,6 +423,19 @@ def self_launch(n: int) -> int:
     env.setdefault("OMP_NUM_THREADS", str(max(1, host_threads() // n)))
     log(f"[bench] --gpus {n} without WORLD_SIZE: launching {n} ranks: {' '.join(cmd)}")
     return subprocess.run(cmd, env=env).returncode
+
+
+def kernel_source_sha16() -> str:
+    """Identity of the dominant kernel's build: sha256 over the sources of its translation unit and the build flags
+    (toyrenderer_amd/csrc: k_basepass_as.hip, cull_math.hip.h, instance_cache.hip.h, ShaderInterop.h, trhip_internal.h,
+    Makefile).  profiles/r3/traffic.json stores the value of the build its counters were collected on."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "toyrenderer_amd", "csrc")
+    for f in ("k_basepass_as.hip", "cull_math.hip.h", "instance_cache.hip.h", "ShaderInterop.h", "trhip_internal.h", "Makefile"):
+        with open(os.path.join(base, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
 
 def host_threads() -> int:
