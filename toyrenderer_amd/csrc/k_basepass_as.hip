@@ -225,6 +225,22 @@ __device__ __forceinline__ void issueMeshletLoads(char* slotLds /* wave-uniform 
 // TABLE: resolve the HZB lookup through the footprint-min table (one 2-byte load; the early pass, where the
 // table is rebuilt once per frame behind the instance pass) or through the texels themselves (two texel-pair
 // loads; the late pass, which is small and follows an HZB rebuild).  Same results either way.
+#ifndef TR_LK_POLICY_ID         /* cache-policy bits of the table lookup (experiments; measured alike, profiles/r3/experiments.md section 8) */
+#define TR_LK_POLICY_ID 0
+#endif
+#if TR_LK_POLICY_ID == 0
+#define TR_LK_POLICY ""
+#elif TR_LK_POLICY_ID == 1
+#define TR_LK_POLICY " sc0"
+#elif TR_LK_POLICY_ID == 2
+#define TR_LK_POLICY " sc1"
+#elif TR_LK_POLICY_ID == 3
+#define TR_LK_POLICY " sc0 sc1"
+#elif TR_LK_POLICY_ID == 4
+#define TR_LK_POLICY " nt"
+#else
+#define TR_LK_POLICY " sc1 nt"
+#endif
 #ifndef TR_CULL_WAVES_PER_EU
 #define TR_CULL_WAVES_PER_EU 4   /* waves per SIMD the register allocation aims at; LDS: 4 workgroups of 33.4 KB per CU (4, 5 and 6 per CU measured alike) */
 #endif
@@ -291,7 +307,11 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
     // meshlet, count} from the tile-ordered list the instance pass wrote, or {record index, instance, lod, group offset}
     // from the record buffer itself.
     auto loadEntry = [&](uint32_t sb_) -> uint4 {
+#ifdef TR_BLOCKED_MAP    /* experiment: wave w takes the window's records [32 w, 32 w + 32) -- the four groups of an instance in two consecutive steps of ONE wave */
+        const uint64_t e64 = (uint64_t)sb_ * superSize + waveInTeam * kCullBatch + lane;
+#else
         const uint64_t e64 = (uint64_t)sb_ * superSize + (lane >> 1) * 2 * teamWaves + 2 * waveInTeam + (lane & 1);
+#endif
         if (lane >= kCullBatch || sb_ >= numSuper || e64 >= G) return make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
         const uint32_t e = (uint32_t)e64;
         if (usePerm) return a.perm[e];
@@ -332,10 +352,16 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
     for (uint32_t it = 0; sb != 0xFFFFFFFFu; ++it, sb = sbNext, s0 = s0n, s1 = s1n) {
         sbNext = windowOf(it + 1u, s0n, s1n);
         const uint32_t sbBase = sb * superSize;
+#ifdef TR_BLOCKED_MAP
+        if (sbBase + waveInTeam * kCullBatch >= G) break;
+        const uint32_t remaining = G - sbBase - waveInTeam * kCullBatch;
+        uint32_t nSteps = (remaining + 1u) / 2u;
+#else
         if (sbBase + 2 * waveInTeam >= G) break;                                     // nothing left for this wave
         // steps of this window that still hold records for this wave (wave-uniform), rounded up to whole trips round the ring
         const uint32_t remaining = G - sbBase - 2 * waveInTeam;
         uint32_t nSteps = (remaining + 2 * teamWaves - 1) / (2 * teamWaves);
+#endif
         nSteps = nSteps < kCullSteps ? (nSteps + kRingSlots - 1u) / kRingSlots * kRingSlots : kCullSteps;
         nSteps = nSteps < s1 ? nSteps : s1;                                          // this team's piece of the window: steps [s0, nSteps)
         if (s0 >= nSteps) break;                                                     // (only a piece of the partial last window can be empty: the last iteration)
@@ -425,7 +451,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
             const unsigned long long m = want | 1ull;
             unsigned long long sv;
             if (TABLE)
-                asm volatile("s_mov_b64 %[sv], exec\n\ts_and_b64 exec, exec, %[m]\n\tglobal_load_ushort %[d], %[a], off\n\ts_mov_b64 exec, %[sv]"
+                asm volatile("s_mov_b64 %[sv], exec\n\ts_and_b64 exec, exec, %[m]\n\tglobal_load_ushort %[d], %[a], off" TR_LK_POLICY "\n\ts_mov_b64 exec, %[sv]"
                              : [d] "+v"(w0), [sv] "=&s"(sv) : [a] "v"(p0), [m] "s"(m) : "memory", "scc");
             else
                 asm volatile("s_mov_b64 %[sv], exec\n\ts_and_b64 exec, exec, %[m]\n\tglobal_load_dword %[d0], %[a0], off\n\tglobal_load_dword %[d1], %[a1], off\n\ts_mov_b64 exec, %[sv]"
@@ -492,6 +518,9 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
 #ifdef TR_NO_LOOKUP      /* experiment, results WRONG: what the kernel would cost if the lookups were free */
                 issueLookup(lk0[kSlot], lk1[kSlot], a.quad.base, a.quad.base, 0ull);
                 asm volatile("" :: "v"(entry));
+#elif defined(TR_EXP_LK_MODE)   /* experiment, results WRONG: 1 = every lane of a lookup reads the same line, 2 = the lanes' own entries folded into 4 KB (L1 hits) */
+                const uint16_t* e2 = reinterpret_cast<const uint16_t*>(a.quad.base) + (TR_EXP_LK_MODE == 1 ? (lane & 31u) : (oq.iq & 2047u));
+                issueLookup(lk0[kSlot], lk1[kSlot], e2, e2, vis & ~oq.accept);
 #else
                 issueLookup(lk0[kSlot], lk1[kSlot], entry, entry, vis & ~oq.accept);
 #endif
@@ -1212,6 +1241,10 @@ void emitListBuild(const trhip::DispatchCtx& ctx, const MeshletCullArgs& a, cons
     }
     const uint32_t needBlocks = (a.maxBatches + kWaves - 1) / kWaves;
     uint32_t gridSmall = ctx.computeUnits() * 8u;      // count / expand: light kernels, one wave per 64 groups
+    if (side) {                                         // experiment: TRHIP_EXPAND_BLOCKS_PER_CU (side-stream list builds only)
+        static const int perCU = [] { const char* e = getenv("TRHIP_EXPAND_BLOCKS_PER_CU"); return e ? atoi(e) : 0; }();
+        if (perCU > 0) gridSmall = ctx.computeUnits() * (uint32_t)perCU;
+    }
     if (gridSmall > needBlocks) gridSmall = needBlocks;
     if (gridSmall == 0) gridSmall = 1;
     const std::string p = prefix;
