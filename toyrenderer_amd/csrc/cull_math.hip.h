@@ -39,6 +39,9 @@ __device__ __forceinline__ lmask mLt(float a, float b) { lmask m; asm("v_cmp_lt_
 __device__ __forceinline__ lmask mGe(float a, float b) { lmask m; asm("v_cmp_ge_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }   // a >= b (false for NaN)
 __device__ __forceinline__ lmask mAbsGt(float a, float b) { lmask m; asm("v_cmp_gt_f32_e64 %0, |%1|, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }   // |a| > b (false for NaN)
 __device__ __forceinline__ lmask mLeU(uint32_t a, uint32_t b) { lmask m; asm("v_cmp_le_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
+__device__ __forceinline__ lmask mGeU(uint32_t a, uint32_t b) { lmask m; asm("v_cmp_ge_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
+__device__ __forceinline__ lmask mAbsLe(float a, float b) { lmask m; asm("v_cmp_le_f32_e64 %0, |%1|, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }   // |a| <= b (false for NaN)
+__device__ __forceinline__ lmask mNotGt(float a, float b) { lmask m; asm("v_cmp_ngt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }   // !(a > b) (true for NaN)
 
 // Two independent fp32 values in one 64-bit register pair: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 process both
 // in one issue slot (the hot kernel is VALU-issue bound).  Every packed operation below is the same IEEE operation
@@ -318,7 +321,7 @@ __device__ __forceinline__ uint32_t quadIndex(uint32_t offset, uint32_t blockRow
 struct OccQuad
 {
     lmask accept;             // :48-49 (lane mask)
-    bool slow;
+    lmask slow;               // lanes whose lookup the table cannot serve (lane mask; 0 almost always)
     float depthSphere;        // :79
     uint32_t iq;              // table index (always in range: uv is clamped to [0,1] and NaN-free)
 };
@@ -529,20 +532,20 @@ __device__ __forceinline__ void stepQuotients(lmask active, F3 c, float r, uint3
     const uint32_t kLo = 0x0F800000u, kHi = 0x5D800000u;               // 2^-96, 2^60
     uint32_t uMin = 0x3F800000u, uMax = 0x3F800000u;                   // radicands as bit patterns: negative / NaN read as huge
     float mag = 1.0f;
-    bool rOk = true;
+    lmask safe = ~0ull;                                                // lane masks straight from the compares (no bool round trip through a VGPR)
     if (OCC) {
         uMin = min(__float_as_uint(vArg.x), __float_as_uint(vArg.y));
         uMax = max(max(__float_as_uint(vArg.x), __float_as_uint(vArg.y)), uMax);
         mag = min_(min_(minAbs3(n1.x, n1.y, n2.x), minAbs3(n2.y, d1.x, d1.y)), minAbs3(d2.x, d2.y, dz));
-        rOk = __builtin_fabsf(r) <= 0x1p30f;                           // false for NaN
+        safe = mGe(mag, 0x1p-30f) & mAbsLe(r, 0x1p30f);                // both false for NaN
     }
     if (CONE) {
         uMin = min(min(__float_as_uint(st), __float_as_uint(sc)), uMin);
         uMax = max(max(__float_as_uint(st), __float_as_uint(sc)), uMax);
     }
-    const bool safe = (uMin >= kLo) & (uMax <= kHi) & (mag >= 0x1p-30f) & rOk & nearInRange;
+    safe &= mGeU(uMin, kLo) & mLeU(uMax, kHi);
     o.coneExact = false;
-    if (__builtin_expect((__builtin_amdgcn_ballot_w64(!safe) & active) != 0ull, 0)) {
+    if (__builtin_expect((active & ~safe) != 0ull || !nearInRange, 0)) {
         // ---- EXACT path (rare): the compiler's full square root / division sequences, as before ---------------------
         TR_PATH_COUNT(true);
         o.coneExact = true;
@@ -670,11 +673,12 @@ __device__ __forceinline__ OccQuad occTailQuad(const StepQuot& q, F3 c, float r,
     // A zero weight drops the second column (row) from the footprint; that only changes the set of texels when the
     // second column (row) is a different texel after edge clamping, i.e. 0 <= x0 and x0 + 1 <= mw - 1.  Rare: only a
     // wave that has an exactly integral coordinate somewhere looks at the rest of the condition.
-    const bool zx = !(f.x > flx), zy = !(f.y > fly);
-    o.slow = false;
-    if (__builtin_expect(__ballot(zx | zy) != 0ull, 0)) {
+    const lmask zx = mNotGt(f.x, flx), zy = mNotGt(f.y, fly);
+    o.slow = 0ull;
+    if (__builtin_expect((zx | zy) != 0ull, 0)) {
         const int mw = (int)__uint_as_float(tab.z), mh = (int)__uint_as_float(tab.w);
-        o.slow = (zx & (x0 >= 0) & (x0 + 1 < mw)) | (zy & (y0 >= 0) & (y0 + 1 < mh));
+        const bool bx = !(f.x > flx), by = !(f.y > fly);
+        o.slow = __builtin_amdgcn_ballot_w64((bx & (x0 >= 0) & (x0 + 1 < mw)) | (by & (y0 >= 0) & (y0 + 1 < mh)));
     }
     o.depthSphere = q.depthSphere;
     return o;

@@ -526,8 +526,8 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
 #endif
                 // A lookup whose footprint is NOT the table's (a zero bilinear weight) is only noted here and the
                 // meshlet is re-evaluated with the texel path after the batch (fixups below).  Rare.
-                if (__builtin_expect(__ballot(oq.slow) != 0ull, 0)) {
-                    if (oq.slow) {
+                if (__builtin_expect(oq.slow != 0ull, 0)) {
+                    if ((oq.slow >> lane) & 1ull) {
                         const uint32_t idx = atomicAdd(&s_slowCount[wave], 1u);
                         if (idx < kSlowCap) s_slow[idx] = (r << 5) | sub;
                     }
@@ -654,7 +654,10 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
 // batches before it in its super (at most four loads per lane).  The single-workgroup scan over ALL batches was 20 us on
 // C3 (27 k batches), during which the expansion it delayed ran into the late meshlet cull.  (Per-super sums by
 // device-scope atomics instead: 27 k atomics on 107 addresses took 100 us and stalled the HZB build next to them.)
-constexpr uint32_t kSuperShift = 8;
+#ifndef TR_SUPER_SHIFT
+#define TR_SUPER_SHIFT 8
+#endif
+constexpr uint32_t kSuperShift = TR_SUPER_SHIFT;
 constexpr uint32_t kSuperBatches = 1u << kSuperShift;
 constexpr uint32_t kCountThreads = 1024;
 constexpr uint32_t kCountWaves = kCountThreads / 64;
