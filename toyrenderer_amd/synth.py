@@ -98,6 +98,10 @@ class SceneSpec:
     mesh_size: float = 2.0
     seed: int = SEED_SCENE
     chunk_meshes: int = 32768
+    # order of the meshlets inside a (mesh, LOD) range: "random" (positions drawn independently: consecutive meshlets are
+    # anywhere in the mesh -- the BASELINE configs) or "morton" (the same meshlets sorted along a Z-order curve through the
+    # mesh's box, the spatial coherence a meshlet builder's output has: a group of 32 covers a fraction of the mesh)
+    meshlet_order: str = "random"
 
 
 def _rng(seed: int, stream: int, chunk: int) -> np.random.Generator:
@@ -164,6 +168,20 @@ def gen_meshlets_for_meshes(spec: SceneSpec, md: np.ndarray, mesh_begin: int, me
     ml["m_MeshletVertexIDsBufferIdx"] = bits[:, 1] >> 1
     ml["m_MeshletIndexIDsBufferIdx"] = bits[:, 2] >> 1
     ml["m_VertexAndTriangleCount"] = ((bits[:, 3] & 63) + 1) | ((((bits[:, 3] >> 8) % 96) + 1) << 8)
+    if spec.meshlet_order == "morton":
+        counts = md["m_MeshLODDatas"]["m_NumMeshlets"][mesh_begin:mesh_end].astype(np.int64).ravel()   # (mesh, LOD) ranges in buffer order
+        seg = np.repeat(np.arange(len(counts), dtype=np.int64), counts)
+        q = np.clip(((u[:, :3]) * np.float32(1024.0)).astype(np.int64), 0, 1023)
+
+        def spread(v):                                     # 10 bits -> every third bit
+            v = (v | (v << 16)) & 0x030000FF
+            v = (v | (v << 8)) & 0x0300F00F
+            v = (v | (v << 4)) & 0x030C30C3
+            return (v | (v << 2)) & 0x09249249
+        key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+        ml = ml[np.lexsort((key, seg))]
+    elif spec.meshlet_order != "random":
+        raise ValueError(spec.meshlet_order)
     return ml
 
 
@@ -293,6 +311,8 @@ def config_spec(name: str) -> SceneSpec:
         return SceneSpec(num_meshes=97_656, num_instances=97_656, meshlets_lod0=128, max_lods=1, unique=True)
     if name == "C3r":  # one rank's share of C3 on 8 GPUs: 97 656 x 128 = 12.5 M meshlets, 390 625 groups (< 2^19: the small-pass code paths)
         return SceneSpec(num_meshes=97_656, num_instances=97_656, meshlets_lod0=128, max_lods=1, unique=True)
+    if name == "C3m":  # DIAGNOSTIC: C3 with the meshlets of every mesh in Z-order (what spatial coherence inside a mesh is worth to the HZB lookups)
+        return SceneSpec(num_meshes=781_250, num_instances=781_250, meshlets_lod0=128, max_lods=1, unique=True, meshlet_order="morton")
     if name == "C3s":  # 1/64 of C3 for quick GPU parity runs
         return SceneSpec(num_meshes=12_208, num_instances=12_208, meshlets_lod0=128, max_lods=1, unique=True)
     raise KeyError(name)
