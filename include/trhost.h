@@ -149,7 +149,8 @@ typedef struct trhost_exchange_desc {
 } trhost_exchange_desc;
 int  trhost_exchange_create(const trhost_exchange_desc* desc);   /* also installs the in-frame late-count hook      */
 int  trhost_exchange_run(void);                                  /* after trhost_frame: pack, gather, unpack (async) */
-int  trhost_exchange_wait(void);
+int  trhost_exchange_wait(void);                                 /* until the last run's results are complete; fails if the unpack flagged a
+                                                                  * pass slot (status word 7 of its arguments: slot overflow, capacity, header, drop) */
 /* trhip_buffer handles of the whole-scene results of a pass slot: records, lane masks, ordered visible list,
  * args (8 words: {G,1,1,G}, {V,1,1}, status bits as in gather.py). */
 int  trhost_exchange_outputs(uint32_t pass_slot, void** records, void** masks, void** list, void** args);

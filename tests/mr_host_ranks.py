@@ -168,6 +168,33 @@ def main():
             ex.close()
         finally:
             r.shutdown()
+    elif mode == "overflow":
+        # a shard slot too small for a rank's groups poisons the frame (status bit 1 in the unpacked arguments):
+        # trhost_exchange_wait must report it instead of handing out a silently wrong frame.
+        render = (640, 360)
+        spec = synth.SceneSpec(num_meshes=24, num_instances=600, meshlets_lod0=70, jitter_meshlets=True, max_lods=2, seed=99)
+        scene = synth.make_scene(spec)
+        view = synth.make_view(eye=(0.5, 0.2, 1.0), yaw=0.03, render=render)
+        op = scene.opaqueIds
+        a, b = shard_range(len(op), rank, world)
+        cap = 8192
+        r = host.Renderer(render=render, max_groups=cap)
+        try:
+            r.load_scene(scene.instances, scene.meshData, scene.meshlets, op[a:b], np.zeros(0, np.uint32))
+            r.set_culling(5)
+            ex = NativeShardExchange(r, dist, world, rank, slot_groups=64, pass_slots=(0,), group_capacity=cap, stage_through_host=True, slot_runs=len(op))
+            r.set_camera(view)
+            r.frame()
+            ex.run()
+            try:
+                ex.wait()
+            except host.HostError as e:
+                assert "status" in str(e) and "slot_groups" in str(e), e
+            else:
+                raise AssertionError("an overflowed shard slot went unreported")
+            ex.close()
+        finally:
+            r.shutdown()
     else:
         raise SystemExit(f"unknown mode {mode}")
     dist.barrier()

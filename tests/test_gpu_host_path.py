@@ -266,6 +266,12 @@ def test_ranks_with_different_kinds_of_lists(world, tmp_path):
     assert out.count("uneven: ok") == world
 
 
+def test_an_overflowed_shard_slot_is_reported_by_the_exchange(tmp_path):
+    """trhost_exchange_wait reads the unpacked status words; a slot too small for a rank's groups is an error."""
+    out = _run_ranks(2, "overflow", tmp_path)
+    assert out.count("overflow: ok") == 2
+
+
 def test_sharded_raster_depth_equals_single_gpu(tmp_path):
     """with self-rasterised depth every rank draws only its shard; the depth buffers are MAX-combined across the
     ranks before each HZB build, so lists, depth and HZB equal the single-GPU frame -- and without the reduction the

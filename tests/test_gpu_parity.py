@@ -441,6 +441,72 @@ def test_randomised_small_scene_sweep(dev, oracle, block):
             raise AssertionError(f"case {case}: {spec} render={render} flags={flags} forced={forced} cap={cap}: {e}") from e
 
 
+@pytest.mark.parametrize("flags,mid_cap", [(7, False), (3, False), (7, True)])
+def test_instance_pass_continues_from_nonzero_counters(dev, oracle, flags, mid_cap):
+    """gpuculling.hlsl:64-66, 165: the pass ADDS to whatever the group counter and the late counter hold.  Two dispatches
+    (the opaque list, then the alpha-mask list) into the SAME record / counter / late-list buffers with no clear in between:
+    the second pass starts from the first one's counters.  The single-launch pass reads those starting values while its last
+    tile rewrites them (k_gpuculling.hip instanceFusedKernel); test_three_kernel_instance_pass_on_small_scenes
+    runs this case through the three-kernel path as well.  mid_cap: a group capacity between the two passes' counters -- the
+    second pass starts below it and drops at it (Q2)."""
+    from toyrenderer_amd.frame import FrameDriver, GpuScene
+    from toyrenderer_amd.rhi import CB, SRV, UAV, TEX_SRV, SAMPLER
+    view = synth.make_view(eye=(0.3, 0.1, 0.6), yaw=0.02, render=(640, 360))
+    spec = synth.SceneSpec(num_meshes=20, num_instances=700, meshlets_lod0=60, jitter_meshlets=True, max_lods=3,
+                           alpha_mask_fraction=0.4, seed=91)
+    scene = synth.make_scene(spec)
+    d_prev = synth.gen_depth(view, num_occluders=70, seed=5, scale=3.0)
+    hzb = _oracle_hzb(oracle, view, d_prev)
+    gs = GpuScene(dev, scene.instances, scene.meshData, scene.meshlets, scene.opaqueIds, scene.alphaMaskIds)
+    lists = [(gs.opaqueIds, gs.numOpaque, scene.opaqueIds), (gs.alphaMaskIds, gs.numAlphaMask, scene.alphaMaskIds)]
+    assert all(n > 0 for _, n, _ in lists)
+    probe = FrameDriver(dev, gs, view, record_capacity=16, culling_flags=flags)       # only for its constants
+
+    def oracle_passes(cap):
+        recs = np.zeros(cap, oracle.RECORD_DT)
+        o_args, o_late, o_ids = np.zeros(3, np.uint32), np.zeros(1, np.uint32), np.zeros(len(scene.instances), np.uint32)
+        xs, valid = [], 0
+        for _, nb, ids in lists:
+            valid = oracle.instance_cull(probe._cull_consts(nb), False, scene.instances, ids, scene.meshData, hzb, recs, o_args, o_late, o_ids, 0, cap)
+            xs.append(int(o_args[0]))
+        return recs, o_args, int(o_late[0]), o_ids, xs, valid
+    _, _, _, _, xs, _ = oracle_passes(65535)
+    assert 0 < xs[0] < xs[1], "both passes must submit groups"
+    cap = (xs[0] + xs[1]) // 2 if mid_cap else 65535
+    recs, o_args, o_late, o_ids, xs, valid = oracle_passes(cap)
+    probe.release()
+    drv = FrameDriver(dev, gs, view, record_capacity=cap, culling_flags=flags)
+    _upload_hzb(drv, hzb)
+    try:
+        cl = drv.cl
+        cl.open()
+        cl.clear_buffer_u32(drv.dispatchArgs[0], 0)
+        cl.clear_buffer_u32(drv.lateCount, 0)
+        cl.clear_buffer_u32(drv.lateIds, 0)
+        for ids_buf, nb, _ in lists:
+            cb = cl.constant_buffer(drv._cull_consts(nb), "GPUCullingPassConstants")
+            b = [CB(0, cb), SRV(0, gs.instances), SRV(1, ids_buf), SRV(2, gs.meshData), UAV(0, drv.records[0]),
+                 UAV(1, drv.dispatchArgs[0]), UAV(2, drv.lateCount), UAV(3, drv.lateIds), SAMPLER(0), TEX_SRV(3, drv.hzb)]
+            cl.dispatch("gpuculling_CS_GPUCulling LATE_CULL=0", b, ((nb + 31) // 32, 1, 1))
+        cl.close()
+        dev.execute(cl)
+        dev.wait_idle()
+        args = drv.dispatchArgs[0].download(np.uint32, 4)
+        late_n = int(drv.lateCount.download(np.uint32, 1)[0])
+        assert int(args[0]) == xs[1] and late_n == o_late, (args, xs, late_n, o_late)
+        if flags & 2:
+            assert late_n > 0
+            assert np.array_equal(drv.lateIds.download(np.uint32, late_n), o_ids[:late_n])
+        assert int(args[3]) == valid, (args, valid)
+        G = min(int(args[0]), int(args[3]), cap)
+        if mid_cap:
+            assert xs[0] < G < cap < int(args[0]), "the second pass must start below the capacity and drop at it"
+        assert np.array_equal(drv.records[0].download(I.MeshletAmplificationData, G).view(np.uint32), recs[:G].view(np.uint32))
+    finally:
+        drv.release()
+        gs.release()
+
+
 def test_three_kernel_instance_pass_on_small_scenes():
     """Small passes run classify + scan + emit as ONE launch (instanceFusedKernel); the three-kernel path then only sees
     the full-size configs.  TRHIP_NO_FUSED_INSTANCE=1 sends the small cases of this file through it as well."""
@@ -450,7 +516,7 @@ def test_three_kernel_instance_pass_on_small_scenes():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, TRHIP_NO_FUSED_INSTANCE="1")
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
-                        "-k", "all_flag or late_dispatch or group_cap or two_frames or sweep or empty or forced"],
+                        "-k", "all_flag or late_dispatch or group_cap or two_frames or sweep or empty or forced or continues_from"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
 

@@ -263,6 +263,17 @@ void ShardExchangeWait()
     check(g_Exchange);
     require(trhip_device_wait_idle(g_Exchange->commDev), "exchange: wait");
     require(trhip_stream_synchronize(g_Exchange->auxStream), "exchange: wait (aux)");
+    // A slot that overflowed, a corrupt header, a whole-scene buffer too small, a rank that dropped groups at its capacity
+    // without a global capacity to cut at: the unpack flags them in word 7 of the pass slot's arguments (gather.py STATUS_*).
+    // Such a frame must not be consumed silently.
+    for (uint32_t s = 0; s < kMaxPassSlots; ++s) {
+        if (!g_Exchange->wants(s) || !g_Exchange->args[s]) continue;
+        uint32_t status = 0;
+        require(trhip_buffer_download(g_Exchange->args[s], 7 * sizeof(uint32_t), &status, sizeof status), "exchange: read status");
+        if (status != 0)
+            throw nvrhi::Error("shard exchange: pass slot " + std::to_string(s) + " failed with status " + std::to_string(status) +
+                               " (1 a rank's groups exceed slot_groups, 2 whole-scene capacity exceeded, 4 corrupt slot header, 8 a rank dropped groups at its capacity)");
+    }
 }
 
 void ShardExchangeOutputs(uint32_t slot, void** records, void** masks, void** list, void** args)
