@@ -49,13 +49,16 @@ inline InstanceCullCache instanceCacheLayout(void* base, uint64_t n)
 // the mesh-space bounding sphere: what instanceCacheKernel writes, and what the transform update re-writes in place
 // (k_updateinstance.hip) so that an animated frame does not re-read 300 B per instance to rebuild the whole cache.
 // Needs cull_math.hip.h before this header.
-__device__ __forceinline__ void instanceCacheWriteTransformPart(const InstanceCullCache& c, uint32_t i, float4 w0, float4 w1, float4 w2, float4 w3, float4 sph)
+// worldOut: where the 64-byte world block goes (default: its place in the cache; the transform update stages a workgroup's
+// blocks in LDS and stores them whole lines at a time).
+__device__ __forceinline__ void instanceCacheWriteTransformPart(const InstanceCullCache& c, uint32_t i, float4 w0, float4 w1, float4 w2, float4 w3, float4 sph,
+                                                                float4* worldOut = nullptr)
 {
     const cm::M43 W = { { w0.x, w0.y, w0.z }, { w1.x, w1.y, w1.z }, { w2.x, w2.y, w2.z }, { w3.x, w3.y, w3.z } };
     const float ms = cm::maxScale(W.r0, W.r1, W.r2);                                 // toyrenderer_common.hlsli:134-140
     const cm::F3 wc = cm::mulPoint({ sph.x, sph.y, sph.z }, W);                      // gpuculling.hlsl:116 TransformBoundingSphereToWorld
     const_cast<float4*>(c.sphere)[i] = make_float4(wc.x, wc.y, wc.z, sph.w * ms);
-    float4* wr = const_cast<float4*>(c.world) + 4ull * i;
+    float4* wr = worldOut ? worldOut : const_cast<float4*>(c.world) + 4ull * i;
     wr[0] = make_float4(w0.x, w0.y, w0.z, w1.x);
     wr[1] = make_float4(w1.y, w1.z, w2.x, w2.y);
     wr[2] = make_float4(w2.z, w3.x, w3.y, w3.z);

@@ -8,6 +8,8 @@
 // HBM traffic per instance: 4 B node id + 48 B per hierarchy level + 64 B read + 128 B written; + 16 B read and 84 B
 // written when the kernel also refreshes the transform-dependent entries of the instance cull cache (instance_cache.hip.h)
 // -- otherwise the next cull pass rebuilds the whole cache: 300 B read + 200 B written per instance, every animated frame.
+#include <cstddef>
+
 #include "cull_math.hip.h"
 #include "instance_cache.hip.h"
 #include "trhip_internal.h"
@@ -53,35 +55,92 @@ __device__ __forceinline__ M44 makeWorldMatrix(const NodeLocalTransform& t)
     return matmul(matmul(R, S), T);
 }
 
-__global__ __launch_bounds__(256) void updateInstanceConstsKernel(const NodeLocalTransform* __restrict__ nodes, uint32_t numNodes,
-                                                                  const uint32_t* __restrict__ primToNode,
-                                                                  BasePassInstanceConstants* instances, uint32_t n,
-                                                                  bool refreshCache, InstanceCullCache cache)
+// A workgroup owns 256 consecutive instances = 36 864 contiguous bytes of the instance buffer.  The records are 144 bytes
+// (two matrices + 16 bytes this pass never touches): a thread per instance reading / writing its own record moves 16 bytes
+// per lane at a stride of 144 -- every wave instruction touches 64-72 lines for 1 KB of data, and every line is written in
+// eight pieces (100 us on C3, 0.43 of what the bytes need).  Instead the block's records travel whole lines at a time through
+// LDS: loaded with consecutive lanes on consecutive 16 bytes, updated in place in LDS (:35-36), stored the same way; the cull
+// cache's 64-byte world blocks of the 256 instances (16 KB contiguous) leave through LDS as well.
+#ifndef TR_UPD_BLOCK
+#define TR_UPD_BLOCK 256
+#endif
+constexpr uint32_t kUpdBlock = TR_UPD_BLOCK;
+constexpr uint32_t kRecVec = sizeof(BasePassInstanceConstants) / 16;            // 9 float4 per record
+static_assert(sizeof(BasePassInstanceConstants) % 16 == 0 && offsetof(BasePassInstanceConstants, m_PrevWorldMatrix) == 64, "record layout");
+
+__global__ __launch_bounds__(kUpdBlock) void updateInstanceConstsKernel(const NodeLocalTransform* __restrict__ nodes, uint32_t numNodes,
+                                                                        const uint32_t* __restrict__ primToNode,
+                                                                        BasePassInstanceConstants* instances, uint32_t n,
+                                                                        bool refreshCache, InstanceCullCache cache)
 {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;                                                           // :13-16
-    const uint32_t nodeID = primToNode[i];                                        // :19
-    if (nodeID >= numNodes) return;                                               // never read outside the node buffer
-    NodeLocalTransform lt = nodes[nodeID];                                        // :20
-    M44 world = makeWorldMatrix(lt);                                              // :22
-    uint32_t parent = lt.m_ParentNodeIdx;                                         // :24
-    uint32_t guard = 0;
-    while (parent != 0xFFFFFFFFu && parent < numNodes && guard++ < 1024) {       // :25-32 (bounded: a cyclic hierarchy must not hang the GPU)
-        const NodeLocalTransform pt = nodes[parent];
-        world = matmul(world, makeWorldMatrix(pt));
-        parent = pt.m_ParentNodeIdx;
-    }
-    float4* w = reinterpret_cast<float4*>(&instances[i].m_WorldMatrix);
-    float4* p = reinterpret_cast<float4*>(&instances[i].m_PrevWorldMatrix);
-    float4 rows[4];
+    __shared__ float4 s_rec[kUpdBlock * kRecVec];                                // the block's instance records
+    __shared__ float4 s_world[kUpdBlock * 4];                                    // the block's cull-cache world blocks
+    const uint32_t tid = threadIdx.x;
+    const uint32_t i0 = blockIdx.x * kUpdBlock;
+    const uint32_t cnt = n - i0 < kUpdBlock ? n - i0 : kUpdBlock;                // (the grid covers [0, n))
+    const uint32_t i = i0 + tid;
+    const bool mine = tid < cnt;
+    // requests first: the node id (and, behind it, the node), the block's records
+    const uint32_t nodeID = mine ? primToNode[i] : 0xFFFFFFFFu;                  // :19
+    float4* g = reinterpret_cast<float4*>(instances + i0);
+    float4 v[kRecVec];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        rows[r] = make_float4(world.m[r][0], world.m[r][1], world.m[r][2], world.m[r][3]);
-        p[r] = w[r];                                                              // :35
-        w[r] = rows[r];                                                           // :36
+    for (uint32_t k = 0; k < kRecVec; ++k) {
+        const uint32_t e = k * kUpdBlock + tid;
+        v[k] = e < cnt * kRecVec ? g[e] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // the cull cache's view of this instance, from the same four rows the cache builder would read back
-    if (refreshCache) instanceCacheWriteTransformPart(cache, i, rows[0], rows[1], rows[2], rows[3], cache.localSphere[i]);
+    const bool valid = mine && nodeID < numNodes;                                // never read outside the node buffer
+    NodeLocalTransform lt = {};
+    float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) lt = nodes[nodeID];                                               // :20
+    if (valid && refreshCache) sph = cache.localSphere[i];
+#pragma unroll
+    for (uint32_t k = 0; k < kRecVec; ++k) s_rec[k * kUpdBlock + tid] = v[k];
+    M44 world = {};
+    if (valid) {
+        world = makeWorldMatrix(lt);                                             // :22
+        uint32_t parent = lt.m_ParentNodeIdx;                                    // :24
+        uint32_t guard = 0;
+        while (parent != 0xFFFFFFFFu && parent < numNodes && guard++ < 1024) {  // :25-32 (bounded: a cyclic hierarchy must not hang the GPU)
+            const NodeLocalTransform pt = nodes[parent];
+            world = matmul(world, makeWorldMatrix(pt));
+            parent = pt.m_ParentNodeIdx;
+        }
+    }
+    __syncthreads();
+    if (valid) {
+        float4* rec = s_rec + tid * kRecVec;
+        float4 rows[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rows[r] = make_float4(world.m[r][0], world.m[r][1], world.m[r][2], world.m[r][3]);
+            rec[4 + r] = rec[r];                                                 // :35 Prev = World
+            rec[r] = rows[r];                                                    // :36 World = new
+        }
+        // the cull cache's view of this instance, from the same four rows the cache builder would read back
+        if (refreshCache) instanceCacheWriteTransformPart(cache, i, rows[0], rows[1], rows[2], rows[3], sph, s_world + 4u * tid);
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < kRecVec; ++k) {
+        const uint32_t e = k * kUpdBlock + tid;
+        if (e < cnt * kRecVec) g[e] = s_rec[e];
+    }
+    if (refreshCache) {
+        // An instance without a valid node keeps its cache entry: only whole blocks of valid instances leave through LDS.
+        float4* cw = const_cast<float4*>(cache.world) + 4ull * i0;
+        const bool all = __syncthreads_and(valid || !mine) != 0;
+        if (all) {
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                const uint32_t e = k * kUpdBlock + tid;
+                if (e < cnt * 4u) cw[e] = s_world[e];
+            }
+        } else if (valid) {
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) cw[4u * tid + k] = s_world[4u * tid + k];
+        }
+    }
 }
 
 int recordUpdateInstanceConsts(trhip::DispatchCtx& ctx)
@@ -114,7 +173,7 @@ int recordUpdateInstanceConsts(trhip::DispatchCtx& ctx)
                              instances->cullCacheBytes >= (instances->byteSize / sizeof(BasePassInstanceConstants)) * kInstanceCacheBytesPerInstance &&
                              !getenv("TRHIP_NO_CACHE_REFRESH");
         const InstanceCullCache cache = refresh ? instanceCacheLayout(instances->cullCache, instances->byteSize / sizeof(BasePassInstanceConstants)) : InstanceCullCache{};
-        hipLaunchKernelGGL(updateInstanceConstsKernel, dim3((n + 255) / 256), dim3(256), 0, s, np, numNodes, pn, ip, n, refresh, cache);
+        hipLaunchKernelGGL(updateInstanceConstsKernel, dim3((n + kUpdBlock - 1) / kUpdBlock), dim3(kUpdBlock), 0, s, np, numNodes, pn, ip, n, refresh, cache);
         if (refresh) instances->cullCacheInstVersion = now;
         return trhip::launchStatus("updateInstanceConstsKernel"); });
     return TRHIP_OK;
