@@ -650,7 +650,7 @@ __device__ __forceinline__ v2f occClampUv(v2f m, v2f P)
 }
 
 // Footprint-min table path.  mipTab[e], e = floor(log2(max(w, h, 1))) + 1 clamped to `mips` (what v_frexp_exp returns):
-// { first table entry of mip e-1, its block-row stride (64 * blocks per row), (float)width, (float)height }.
+// { first table entry of mip e-1, its block-row stride (64 * blocks per row), 0.5 * width, 0.5 * height }.
 __device__ __forceinline__ OccQuad occTailQuad(const StepQuot& q, F3 c, float r, float nearPlane, float P00, float P11, const Hzb& h,
                                                const uint4* mipTab, uint32_t quadTotal)
 {
@@ -665,8 +665,10 @@ __device__ __forceinline__ OccQuad occTailQuad(const StepQuot& q, F3 c, float r,
     e = e < (int)h.mips ? e : (int)h.mips;
     e = e > 1 ? e : 1;
     const uint4 tab = mipTab[e];
-    const v2f uv = (lo + hi) * splat2(0.5f);                           // :78
-    const v2f f = fma2(uv, v2f{ __uint_as_float(tab.z), __uint_as_float(tab.w) }, splat2(-0.5f));
+    // :78 uv = (lo + hi) * 0.5 (exact: lo + hi is 0 or >= 2^-25), then fma(uv, dim, -0.5) = RN(uv * dim - 0.5).  dim / 2 is
+    // a float too, and (lo + hi) * (dim / 2) is the same real number as uv * dim: fma(lo + hi, dim / 2, -0.5) rounds the same
+    // exact value -- the table holds dim / 2
+    const v2f f = fma2(lo + hi, v2f{ __uint_as_float(tab.z), __uint_as_float(tab.w) }, splat2(-0.5f));
     const float flx = __builtin_floorf(f.x), fly = __builtin_floorf(f.y);
     const int x0 = (int)flx, y0 = (int)fly;                            // in [-1, mw-1] x [-1, mh-1]
     o.iq = min(quadIndex(tab.x, tab.y, (uint32_t)(x0 + 1), (uint32_t)(y0 + 1)), quadTotal - 1u);
@@ -676,7 +678,7 @@ __device__ __forceinline__ OccQuad occTailQuad(const StepQuot& q, F3 c, float r,
     const lmask zx = mNotGt(f.x, flx), zy = mNotGt(f.y, fly);
     o.slow = 0ull;
     if (__builtin_expect((zx | zy) != 0ull, 0)) {
-        const int mw = (int)__uint_as_float(tab.z), mh = (int)__uint_as_float(tab.w);
+        const int mw = (int)(2.0f * __uint_as_float(tab.z)), mh = (int)(2.0f * __uint_as_float(tab.w));
         const bool bx = !(f.x > flx), by = !(f.y > fly);
         o.slow = __builtin_amdgcn_ballot_w64((bx & (x0 >= 0) & (x0 + 1 < mw)) | (by & (y0 >= 0) & (y0 + 1 < mh)));
     }

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
     if (TABLE && tid >= 1 && tid <= 16) {
         const uint32_t mip = tid - 1u < a.hzb.mips ? tid - 1u : 0u;
         const uint32_t mw = (a.hzb.width >> mip) ? (a.hzb.width >> mip) : 1u, mh = (a.hzb.height >> mip) ? (a.hzb.height >> mip) : 1u;
-        s_mipTab[tid] = make_uint4(a.quad.offset[mip], ((mw >> 3) + 1u) * 64u, __float_as_uint((float)mw), __float_as_uint((float)mh));
+        s_mipTab[tid] = make_uint4(a.quad.offset[mip], ((mw >> 3) + 1u) * 64u, __float_as_uint(0.5f * (float)mw), __float_as_uint(0.5f * (float)mh));
     }
     // the fast arithmetic path wants nearPlane in [2^-20, 2^20] (cm::stepQuotients)
     const bool nearInRange = a.k.m_NearPlane >= 0x1p-20f && a.k.m_NearPlane <= 0x1p20f;
