@@ -415,7 +415,9 @@ def test_randomised_small_scene_sweep(dev, oracle, block):
     render sizes, 1-2 frames): every output word and the HZB chain against the oracle.  Shakes the boundaries the named
     cases do not sit on (list tiles of exactly 2048 groups, one-group passes, empty late lists, ...)."""
     renders = [(640, 360), (100, 40), (1280, 720), (333, 517), (64, 64), (1920, 1080), (2048, 64)]
-    for case in range(block * 12, block * 12 + 12):
+    import os
+    off = int(os.environ.get("TR_SWEEP_OFFSET", "0"))            # soak runs: other 48 configurations (tools/soak_sweep.sh)
+    for case in range(off + block * 12, off + block * 12 + 12):
         rng = np.random.default_rng(1000 + case)
         n_inst = int(rng.choice([1, 2, 31, 32, 33, 64, 255, 500, 1024, 2048, 3000]))
         m0 = int(rng.choice([1, 31, 32, 33, 64, 70, 128, 200]))
@@ -432,6 +434,8 @@ def test_randomised_small_scene_sweep(dev, oracle, block):
         need = n_inst * ((2 * m0 + 31) // 32) + 1
         cap = int(rng.choice([65535, need, max(1, need // 3), 2048, 4096]))
         cap = min(cap, 65535)
+        if os.environ.get("TR_SWEEP_TABLE"):                       # soak runs: the footprint-table kernel (record capacity 2^19) instead of the texel-path one
+            cap = 1 << 19
         d_prev = synth.gen_depth(view, num_occluders=int(rng.integers(0, 80)), seed=case, scale=3.0) if rng.integers(0, 4) else None
         d_cur = synth.gen_depth(view, num_occluders=int(rng.integers(0, 80)), seed=case + 500, scale=3.0)
         try:
