@@ -648,6 +648,19 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
 #endif
 }
 
+// Sum over the 64 lanes of a wave, returned in every lane: four DPP row shifts (a row = 16 lanes), two row broadcasts (gfx9
+// DPP), one readlane -- the __shfl_xor butterfly costs six trips through the LDS crossbar (ds_bpermute) per value.
+__device__ __forceinline__ uint32_t waveSum(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);     // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);     // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);     // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);     // row_shr:8: lane 15 of a row = the row's sum
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);    // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);    // row_bcast:31 into rows 2 and 3: lane 63 = the sum
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // Visible meshlets per batch of 64 consecutive records (canonical order): one wave per batch.  Two levels of sums -- per
 // batch and per "super" of 256 batches, a workgroup per super so that both are plain stores -- and a scan over the supers
 // only (visSuperScanKernel: 107 values on C3): the expansion finds a batch's list offset from the super's prefix + the
@@ -680,8 +693,7 @@ __global__ __launch_bounds__(kCountThreads) void visCountKernel(MeshletCullArgs 
         uint32_t mine = 0;
 #pragma unroll
         for (uint32_t i = 0; i < kPerWave; ++i) {
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) pc[i] += __shfl_xor(pc[i], d);
+            pc[i] = waveSum(pc[i]);
             if (lane == 0 && b0 + i < numBatches) a.batchSum[b0 + i] = pc[i];
             mine += pc[i];
         }
@@ -752,9 +764,7 @@ __global__ __launch_bounds__(kBlock) void visExpandKernel(MeshletCullArgs a)
         const uint32_t sb = batch >> kSuperShift;
         uint32_t before = 0;
         for (uint32_t j = (sb << kSuperShift) + lane; j < batch; j += 64u) before += a.batchSum[j];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
-        before += a.superSum[sb];
+        before = waveSum(before) + a.superSum[sb];
         const uint32_t pc = (uint32_t)__popc(mask);
         const uint32_t exc = waveInclusiveScan(pc, lane) - pc + before;
         mo[lane] = make_uint2(mask, exc);
