@@ -124,14 +124,22 @@ __global__ __launch_bounds__(256) void hzbDepthTileKernel(const float* __restric
         const bool wide = W >= 2u;               // the two texels of a row are neighbours (or the same one at a clamped edge):
                                                  // ONE 8-byte load per row (dword-aligned) instead of two scalar loads
         Pair v0[16], v1[16];
-#pragma unroll
-        for (uint32_t it = 0; it < 16; ++it) {
-            const uint32_t ly = it * 4 + (tid >> 6), y = ty * 64 + ly;
+        // The source rows of a wave's 16 output rows are the same for all its lanes: lane j works them out for row j
+        // (one correctly rounded division each, minmaxdownsample.hlsl:20) and the loop reads them with v_readlane -- a
+        // sixteenth of the row arithmetic, and the load addresses get a scalar row base (13.5 -> 13.0 us per build;
+        // the kernel without its depth reads takes 10: profiles/r3/experiments.md section 11).
+        int rowY0, rowY1;
+        {
+            const uint32_t ly = (tid & 15u) * 4 + (tid >> 6), y = ty * 64 + ly;
             const float v = ((float)y + 0.5f) / (float)oh;
             const float fy = cm::fma_(v, (float)H, -0.5f);
-            int y0 = (int)__builtin_floorf(fy);
-            const int y1 = min(max(y0 + 1, 0), (int)H - 1);
-            y0 = min(max(y0, 0), (int)H - 1);
+            const int f0 = (int)__builtin_floorf(fy);
+            rowY1 = min(max(f0 + 1, 0), (int)H - 1);
+            rowY0 = min(max(f0, 0), (int)H - 1);
+        }
+#pragma unroll
+        for (uint32_t it = 0; it < 16; ++it) {
+            const int y0 = __builtin_amdgcn_readlane(rowY0, (int)it), y1 = __builtin_amdgcn_readlane(rowY1, (int)it);
             if (wide) {
                 v0[it] = *reinterpret_cast<const Pair*>(depth + (uint64_t)y0 * W + xl);
                 v1[it] = *reinterpret_cast<const Pair*>(depth + (uint64_t)y1 * W + xl);
