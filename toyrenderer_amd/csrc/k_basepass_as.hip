@@ -99,11 +99,12 @@ struct RecordInfo                                 // per-record invariants parke
     float adjz[3];                                //                               z column
     float maxScale;
     uint32_t first;                               // m_MeshletDataBufferIdx + m_MeshletGroupOffset (0 when the record tests nothing)
-    uint32_t lastOff;                             // byte offset of the last 16-byte chunk of the record's MeshletData: 32 * count - 16
-                                                  // (count = lanes with meshletIdx < m_NumMeshlets, 1..32), or 0 for count 0
+    uint32_t lastOff;                             // 16 * count - 8 (count = lanes with meshletIdx < m_NumMeshlets, 1..32), or 0 for count 0:
+                                                  // lane `sub` is active iff 16 * sub + 8 <= lastOff; min(16 * sub, lastOff) & ~15 is the byte
+                                                  // offset of the sphere it stages (its own, or the record's last one)
 };
-__device__ __forceinline__ uint32_t lastOffOf(uint32_t count) { return count ? 32u * count - 16u : 0u; }
-__device__ __forceinline__ uint32_t countOf(uint32_t lastOff) { return (lastOff + 16u) >> 5; }
+__device__ __forceinline__ uint32_t lastOffOf(uint32_t count) { return count ? 16u * count - 8u : 0u; }
+__device__ __forceinline__ uint32_t countOf(uint32_t lastOff) { return (lastOff + 8u) >> 4; }
 static_assert(sizeof(RecordInfo) == 96, "RecordInfo layout");
 
 __device__ __forceinline__ cm::M43P worldOf(const RecordInfo& ri)
@@ -116,10 +117,24 @@ __device__ __forceinline__ cm::M33P adjugateOf(const RecordInfo& ri)
     return { { ri.adjxy[0], ri.adjxy[1] }, { ri.adjxy[2], ri.adjxy[3] }, { ri.adjxy[4], ri.adjxy[5] }, ri.adjz[0], ri.adjz[1], ri.adjz[2] };
 }
 
+// The MESHLET CULL STREAM: per meshlet the cull reads the bounding sphere (16 B) and the cone word (4 B) of the 32-byte
+// MeshletData record (basepass.hlsl:65, :92) -- the other 12 bytes are the mesh shader's.  The kernel's pace is set by the
+// L1 misses a CU can keep in flight (its 256 lines pending most of the time: TCP_PENDING_STALL 65 %), i.e. by the NUMBER OF
+// LINES it asks for: a derived copy of just those 20 bytes, spheres and cone words as two dense arrays, is 10 lines per
+// 64-meshlet step instead of 16.  Back-end private, like the instance cull cache: built on the device from the bound meshlet
+// buffer, rebuilt when that buffer's version moves (meshlets are static per mesh: in practice once per upload), 20 bytes
+// per meshlet of extra memory (C4: 20 GB next to the 32 GB of MeshletData).
+struct MeshletCullStream
+{
+    const float4* sphere;                         // [numMeshlets]
+    const uint32_t* cone;                         // [numMeshlets]
+};
+
 struct MeshletCullArgs
 {
     BasePassConstants k;
     const MeshletData* meshlets;
+    MeshletCullStream stream;                     // what the cull reads of them: spheres and cone words as dense arrays (below)
     const MeshletAmplificationData* records;
     cm::Hzb hzb;
     cm::HzbQuad quad;                             // footprint-min table of hzb (k_hzb.hip)
@@ -150,37 +165,37 @@ __device__ __forceinline__ uint32_t groupCount(const MeshletCullArgs& a)
 }
 
 typedef float v4f __attribute__((ext_vector_type(4)));
-// The two records of a step (2 x 1 KB of MeshletData) go from memory STRAIGHT INTO LDS (global_load_lds_dwordx4: no
-// VGPRs in between) as whole cache lines: per half-wave, lane `sub` moves 16-byte chunk `sub` (instruction A: meshlets
-// 0-15) and chunk 32 + sub (instruction B: meshlets 16-31) of its record, so every 128-byte line is requested from the L2
-// exactly once, by one instruction.  That matters more than anything else in this kernel: its pace is set by the L1
-// misses a CU can keep in flight (TCP_PENDING_STALL 60-70 % of the cycles, TA busy 85 %: profiles/r2), not by HBM or by
-// VALU issue.  Each lane then reads ITS OWN meshlet's sphere (ds_read_b128) and cone word (ds_read_b32) out of the staged
-// kilobyte.  (Round 1 kept the chunks in VGPRs and completed the (sphere, cone) pairs with DPP swaps, selects and a
-// shuffled ballot: 14 vector + 40 scalar instructions per step.  Loading 16 + 4 bytes per lane directly -- tried first
-// this round -- asks the L2 for every line twice: 5 % SLOWER than round 1 with 25 % fewer instructions executed.)
+// The two records of a step (2 x 32 spheres = 1 KB, 2 x 32 cone words = 256 B of the meshlet cull stream) go from memory
+// STRAIGHT INTO LDS (global_load_lds_dwordx4 / _dword: no VGPRs in between) as whole cache lines: lane (half, sub) moves
+// sphere `sub` and cone word `sub` of record `half`, so every line is requested from the L2 exactly once, by one
+// instruction.  That matters more than anything else in this kernel: its pace is set by the L1 misses a CU can keep in
+// flight (TCP_PENDING_STALL 60-70 % of the cycles), not by HBM or by VALU issue.  Each lane then reads ITS OWN meshlet's
+// sphere (ds_read_b128, consecutive lanes on consecutive 16 bytes) and cone word (ds_read_b32) out of the staged block.
+// (Rounds 2-3 staged the 32-byte MeshletData records themselves: 16 lines per step.  Round 1 kept the chunks in VGPRs and
+// completed the (sphere, cone) pairs with DPP swaps, selects and a shuffled ballot: 14 vector + 40 scalar instructions per
+// step.  Loading 16 + 4 bytes per lane directly from the records asks the L2 for every line twice: 5 % slower than round 1.)
 //
 // The compiler's wait-count pass cannot tell LDS-DMA targets apart (any LDS read after a global_load_lds builtin waits
 // for vmcnt(0), which would serialise the prefetch), so the ring is driven by hand: the loads, the table lookup that
 // shares their counter and every wait on vmcnt in the loop are inline assembly, and the loop contains no other vector
 // memory instruction.  Loads return in order, so a wait "until at most N are outstanding" is exact.
 //
-// LDS layout of a ring slot (2 KB per wave): [0,512) record A chunks 0-31, [512,1024) record B chunks 0-31,
-// [1024,1536) record A chunks 32-63, [1536,2048) record B chunks 32-63.
+// LDS layout of a ring slot (per wave): [0,1024) the spheres of lanes 0..63 (record A: lanes 0-31, record B: 32-63),
+// [1024,1280) their cone words.
 template <bool AFTER_READS = false>
-__device__ __forceinline__ void issueMeshletLoads(char* slotLds /* wave-uniform */, const MeshletData* meshlets, uint32_t firstIdx, uint32_t lastOff, uint32_t sub16 /* 16 * sub */,
+__device__ __forceinline__ void issueMeshletLoads(char* slotLds /* wave-uniform */, const MeshletCullStream& stream, uint32_t firstIdx, uint32_t lastOff, uint32_t sub16 /* 16 * sub */,
                                                   v4f readA = v4f{ 0.f, 0.f, 0.f, 0.f }, uint32_t readB = 0u /* AFTER_READS: what this wave has just read out of the slot */)
 {
-    // Every lane always loads (chunks past the record's end re-read its last chunk): the number of loads in flight never
+    // Every lane always loads (lanes past the record's end re-read its last meshlet): the number of loads in flight never
     // depends on the data, and nothing outside the record is read.
-#ifdef TR_EXP_NOMEM      /* experiment, results WRONG: every wave streams the same 2 KB (cache hits): the kernel without its HBM traffic */
+#ifdef TR_EXP_NOMEM      /* experiment, results WRONG: every wave streams the same block (cache hits): the kernel without its HBM traffic */
     firstIdx &= 63u;
 #endif
-    const char* p = reinterpret_cast<const char*>(meshlets + firstIdx);
-    const char* pa = p + min(sub16, lastOff);                                        // basepass.hlsl:65
-    const char* pb = p + min(sub16 + 512u, lastOff);
+    const uint32_t o = min(sub16, lastOff) & ~15u;                                   // 16 * min(sub, count - 1): basepass.hlsl:65
+    const char* pa = reinterpret_cast<const char*>(stream.sphere) + (((uint64_t)firstIdx << 4) + o);
+    const char* pb = reinterpret_cast<const char*>(stream.cone) + (((uint64_t)firstIdx << 2) + (o >> 2));
     const uint32_t ldsOff = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)slotLds;
-    // nt: the 1.8 GB stream is read once and must not evict the HZB table and the per-record data from the L2s
+    // nt: the 1.1 GB stream is read once and must not evict the HZB table and the per-record data from the L2s
 #ifndef TR_DMA_POLICY_ID
 #define TR_DMA_POLICY_ID 1       /* experiments (profiles/r2/experiments.md): cache policy of the stream */
 #endif
@@ -205,13 +220,13 @@ __device__ __forceinline__ void issueMeshletLoads(char* slotLds /* wave-uniform 
         asm volatile("s_mov_b32 m0, %2\n\t"
                      "global_load_lds_dwordx4 %0, off " TR_DMA_POLICY "\n\t"
                      "s_add_u32 m0, %2, 0x400\n\t"
-                     "global_load_lds_dwordx4 %1, off " TR_DMA_POLICY
+                     "global_load_lds_dword %1, off " TR_DMA_POLICY
                      :: "v"(pa), "v"(pb), "s"(ldsOff), "v"(readA), "v"(readB) : "memory", "m0", "scc");
     else
         asm volatile("s_mov_b32 m0, %2\n\t"
                      "global_load_lds_dwordx4 %0, off " TR_DMA_POLICY "\n\t"
                      "s_add_u32 m0, %2, 0x400\n\t"
-                     "global_load_lds_dwordx4 %1, off " TR_DMA_POLICY
+                     "global_load_lds_dword %1, off " TR_DMA_POLICY
                      :: "v"(pa), "v"(pb), "s"(ldsOff) : "memory", "m0", "scc");
 }
 #define TR_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -431,8 +446,8 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
         // its prefetch: {the other slots' 2 each, lookup, this slot's 2}.  Hence the two waits: vmcnt(2 * (slots - 1))
         // at the top, vmcnt(2) for the lookup.
         char* const ring = s_ring[__builtin_amdgcn_readfirstlane((int)wave)][0];
-        const uint32_t ringOff = (sub < 16u ? 0u : 512u) + half * 512u + sub * 32u;  // this lane's meshlet inside a ring slot
-        const uint32_t sub16 = sub * 16u, subEnd = sub * 32u + 16u;                  // lane constants of the chunk addressing / the "active" test
+        const uint32_t ringOff = lane * 16u, ringOffCone = 1024u + lane * 4u;        // this lane's sphere / cone word inside a ring slot
+        const uint32_t sub16 = sub * 16u, subEnd = sub * 16u + 8u;                   // lane constants of the stream addressing / the "active" test
         // The occlusion lookup of a step (TABLE: one 2-byte table entry; texel path: two texel pairs), issued for the lanes
         // still in the race -- and ALWAYS for lane 0 (any in-range address), so that the instruction issues whatever the
         // data: the hand-counted waits below rely on a fixed number of loads per step.
@@ -484,11 +499,11 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
             if (kDefer) { if (kRingSlots == 3) { if (kLk == 1) TR_WAIT_VMCNT(5); else TR_WAIT_VMCNT(6); } else { if (kLk == 1) TR_WAIT_VMCNT(3); else TR_WAIT_VMCNT(4); } }
             else { if (kRingSlots == 3) TR_WAIT_VMCNT(4); else TR_WAIT_VMCNT(2); }   // this slot has landed
             const v4f sph = *reinterpret_cast<const v4f*>(slot + ringOff);
-            const uint32_t cone = *reinterpret_cast<const uint32_t*>(slot + ringOff + 16u);
+            const uint32_t cone = *reinterpret_cast<const uint32_t*>(slot + ringOffCone);
             const float4 sphere = make_float4(sph.x, sph.y, sph.z, sph.w);
             // prefetch step s + kRingSlots into this slot (past the batch: the padding entries, a harmless re-read of meshlet 0 that
             // keeps the loads unconditional)
-            if (kEarly) issueMeshletLoads<true>(slot, a.meshlets, s_rec[r + 2 * kRingSlots].first, s_rec[r + 2 * kRingSlots].lastOff, sub16, sph, cone);
+            if (kEarly) issueMeshletLoads<true>(slot, a.stream, s_rec[r + 2 * kRingSlots].first, s_rec[r + 2 * kRingSlots].lastOff, sub16, sph, cone);
             const cm::lmask active = cm::mLeU(subEnd, ri.lastOff);                                 // :62-63 meshletIdx < numMeshlets
             cm::lmask vis = active;
             const cm::M43P W = worldOf(ri);
@@ -540,7 +555,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
                 issueLookup(lk0[kSlot], lk1[kSlot], a.hzb.base + os.i0, a.hzb.base + os.i1, vis & ~accept);   // two texel pairs (cm::loadTexelPair)
             }
             // (late prefetch: the slot's LDS reads above have returned, their values were used)
-            if (!kEarly) issueMeshletLoads(slot, a.meshlets, s_rec[r + 2 * kRingSlots].first, s_rec[r + 2 * kRingSlots].lastOff, sub16);
+            if (!kEarly) issueMeshletLoads(slot, a.stream, s_rec[r + 2 * kRingSlots].first, s_rec[r + 2 * kRingSlots].lastOff, sub16);
             TR_STAMP(4);   // lookup + prefetch issue
             if (!OCCLUSION) {
                 resolve(2u * s + 2u, vis, 0ull, false, 0.f, 0u, 0u);
@@ -569,12 +584,12 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
         // lands in s_mask[0], [1].
 #pragma unroll
         for (uint32_t k = 0; k + 1 < kRingSlots; ++k)
-            issueMeshletLoads(ring + 2048u * k, a.meshlets, s_rec[2 * (s0 + k) + half].first, s_rec[2 * (s0 + k) + half].lastOff, sub16);
+            issueMeshletLoads(ring + 2048u * k, a.stream, s_rec[2 * (s0 + k) + half].first, s_rec[2 * (s0 + k) + half].lastOff, sub16);
         if (kDefer) {
             const void* p = TABLE ? (const void*)a.quad.base : (const void*)a.hzb.base;
             issueLookup(lk0[kRingSlots - 1u], lk1[kRingSlots - 1u], p, p, 0ull);
         }
-        issueMeshletLoads(ring + 2048u * (kRingSlots - 1u), a.meshlets, s_rec[2 * (s0 + kRingSlots - 1u) + half].first, s_rec[2 * (s0 + kRingSlots - 1u) + half].lastOff, sub16);
+        issueMeshletLoads(ring + 2048u * (kRingSlots - 1u), a.stream, s_rec[2 * (s0 + kRingSlots - 1u) + half].first, s_rec[2 * (s0 + kRingSlots - 1u) + half].lastOff, sub16);
 #pragma unroll 1
         for (uint32_t s = s0; s < nSteps; s += kRingSlots) {
             step(std::integral_constant<uint32_t, 0>{}, s);
@@ -1280,6 +1295,59 @@ void launchCull(const MeshletCullArgs& a, uint32_t grid, bool table, hipStream_t
     else hipLaunchKernelGGL((meshletCullKernel<F, O, C, false>), dim3(grid), dim3(kCullBlock), 0, s, a);
 }
 
+// ---- the meshlet cull stream (MeshletCullStream): layout, allocation, build ------------------------------------
+constexpr uint64_t kStreamBytesPerMeshlet = 20;
+__host__ __device__ inline MeshletCullStream meshletStreamLayout(void* mem, uint64_t numMeshlets)
+{
+    const uint64_t coneAt = (numMeshlets * 16u + 255u) & ~255ull;                   // the cone words start on a 256-byte boundary
+    return { reinterpret_cast<const float4*>(mem), reinterpret_cast<const uint32_t*>(reinterpret_cast<char*>(mem) + coneAt) };
+}
+inline uint64_t meshletStreamBytes(uint64_t numMeshlets) { return ((numMeshlets * 16u + 255u) & ~255ull) + numMeshlets * 4u; }
+
+__global__ __launch_bounds__(256) void meshletStreamKernel(const MeshletData* __restrict__ meshlets, uint64_t n, MeshletCullStream out)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += stride) {
+        const float4* p = reinterpret_cast<const float4*>(meshlets + i);
+        const float4 sphere = p[0];
+        const uint32_t cone = __float_as_uint(p[1].x);                               // m_ConeAxisAndCutoff: the word behind the sphere
+        const_cast<float4*>(out.sphere)[i] = sphere;
+        const_cast<uint32_t*>(out.cone)[i] = cone;
+    }
+}
+
+int meshletStreamEnsure(trhip_buffer_t* meshlets)
+{
+    const uint64_t n = meshlets->byteSize / sizeof(MeshletData);
+    const uint64_t need = meshletStreamBytes(n);
+    if (meshlets->cullStreamBytes < need) {
+        TRHIP_HIP(hipSetDevice(meshlets->dev->index));
+        if (meshlets->cullStream) {
+            int rc = meshlets->dev->syncAll();
+            if (rc != TRHIP_OK) return rc;
+            (void)hipFree(meshlets->cullStream);
+            meshlets->cullStream = nullptr; meshlets->cullStreamBytes = 0;
+        }
+        TRHIP_HIP(hipMalloc(&meshlets->cullStream, (size_t)need));
+        meshlets->cullStreamBytes = need;
+        meshlets->cullStreamVersion = 0;
+    }
+    return TRHIP_OK;
+}
+
+// at submission time, on the stream of the cull that follows: no-op unless the meshlet buffer was written since the stream was built
+int meshletStreamLaunchBuild(trhip_buffer_t* meshlets, hipStream_t s)
+{
+    const uint64_t v = meshlets->version;
+    if (meshlets->cullStreamVersion == v) return TRHIP_OK;
+    const uint64_t n = meshlets->byteSize / sizeof(MeshletData);
+    const uint64_t blocks = (n + 255u) / 256u;
+    hipLaunchKernelGGL(meshletStreamKernel, dim3((uint32_t)(blocks < 65536u ? (blocks ? blocks : 1u) : 65536u)), dim3(256), 0, s,
+                       (const MeshletData*)meshlets->ptr, n, meshletStreamLayout(meshlets->cullStream, n));
+    meshlets->cullStreamVersion = v;
+    return trhip::launchStatus("meshletStreamKernel");
+}
+
 int recordASMain(trhip::DispatchCtx& ctx)
 {
     // Binding set of BasePassRenderers.cpp:463-479 (t0 instances, t2 mesh data, t4 meshlets,
@@ -1332,6 +1400,10 @@ int recordASMain(trhip::DispatchCtx& ctx)
     }
     if (rc != TRHIP_OK) return rc;
     a.meshlets = (const MeshletData*)meshlets->ptr;
+    TRHIP_REQUIRE(meshlets->byteSize >= sizeof(MeshletData), "%s: empty meshlet buffer", ctx.shaderName);
+    rc = meshletStreamEnsure(meshlets);
+    if (rc != TRHIP_OK) return rc;
+    a.stream = meshletStreamLayout(meshlets->cullStream, meshlets->byteSize / sizeof(MeshletData));
     a.records = (const MeshletAmplificationData*)records->ptr;
     a.dispatchArgs = (const uint32_t*)((const char*)ctx.argsBuffer->ptr + ctx.argsOffset);
     a.argsWords = (ctx.argsBuffer->byteSize - ctx.argsOffset) >= 16 ? 4u : 3u;
@@ -1380,9 +1452,11 @@ int recordASMain(trhip::DispatchCtx& ctx)
     trhip_texture_t* quadOwner = useTable ? hzb : nullptr;
     const bool table = useTable;
     if (quadOwner) ctx.cl->use(quadOwner->quad, ctx.cl->ops.size(), false);     // the kernel reads the table: ordered after a side-stream rebuild
-    ctx.emit("cull", [a, grid, flags, quadOwner, table, instances, meshData](hipStream_t s) {
+    ctx.emit("cull", [a, grid, flags, quadOwner, table, instances, meshData, meshlets](hipStream_t s) {
         {                                                  // no-op unless the instance or mesh buffer was written since the cache was built
             int crc = trhip::instanceCacheLaunchBuild(instances, meshData, s);
+            if (crc != TRHIP_OK) return crc;
+            crc = meshletStreamLaunchBuild(meshlets, s);  // no-op unless the meshlet buffer was written since its stream was built
             if (crc != TRHIP_OK) return crc;
         }
         if (quadOwner) {                                   // no-op unless the HZB was written since its table was built

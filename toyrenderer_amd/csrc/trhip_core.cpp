@@ -441,6 +441,7 @@ void trhip_buffer_release(trhip_buffer b)
         if (b->owns && b->ptr) { (void)hipSetDevice(b->dev->index); (void)hipFree(b->ptr); }
         if (b->sidecar) { (void)hipSetDevice(b->dev->index); (void)hipFree(b->sidecar); }
         if (b->cullCache) { (void)hipSetDevice(b->dev->index); (void)b->dev->syncAll(); (void)hipFree(b->cullCache); }
+        if (b->cullStream) { (void)hipSetDevice(b->dev->index); (void)b->dev->syncAll(); (void)hipFree(b->cullStream); }
         if (b->heap) trhip_heap_release(b->heap);
         delete b;
     }

@@ -111,6 +111,11 @@ struct trhip_buffer_t
     uint64_t cullCacheBytes = 0;
     uint64_t cullCacheInstVersion = 0, cullCacheMeshVersion = 0;
     const void* cullCacheMesh = nullptr;
+    // Meshlet buffers only: the MESHLET CULL STREAM (k_basepass_as.hip), the 20 bytes of each 32-byte MeshletData the cull
+    // reads (bounding sphere, cone word) as two dense arrays; rebuilt when the buffer's version moves.
+    void* cullStream = nullptr;
+    uint64_t cullStreamBytes = 0;
+    uint64_t cullStreamVersion = 0;
     std::atomic<int> rc{1};
 };
 
