@@ -445,6 +445,46 @@ def test_randomised_small_scene_sweep(dev, oracle, block):
             raise AssertionError(f"case {case}: {spec} render={render} flags={flags} forced={forced} cap={cap}: {e}") from e
 
 
+@pytest.mark.parametrize("table", [False, True])
+def test_meshlet_buffer_rewritten_between_frames(dev, oracle, table):
+    """The cull kernel reads a derived copy of the 20 bytes per meshlet it needs (the meshlet cull stream, k_basepass_as.hip),
+    rebuilt when the meshlet buffer's version moves.  Frame 1 on the scene as loaded; then the meshlet buffer is rewritten
+    -- an upload, and a write_buffer command inside the frame's own recording for a part of it -- and frame 2 must see the
+    new spheres and cones (every output word against the oracle on the new data)."""
+    from toyrenderer_amd.frame import FrameDriver, GpuScene
+    view = synth.make_view(eye=(0.2, 0.1, 0.4), yaw=0.01, render=(640, 360))
+    spec = synth.SceneSpec(num_meshes=30, num_instances=500, meshlets_lod0=70, jitter_meshlets=True, max_lods=2, seed=313)
+    scene = synth.make_scene(spec)
+    d = synth.gen_depth(view, num_occluders=50, seed=9, scale=3.0)
+    hzb = _oracle_hzb(oracle, view, d)
+    gs = GpuScene(dev, scene.instances, scene.meshData, scene.meshlets, scene.opaqueIds, scene.alphaMaskIds)
+    drv = FrameDriver(dev, gs, view, record_capacity=(1 << 19) if table else 65535, culling_flags=7)
+    _upload_hzb(drv, hzb)
+    drv.depth.upload_mip(0, d)
+    cap = (1 << 19) if table else 65535
+    try:
+        drv.record(); drv.run()
+        _compare_frame(drv.results(), oracle.frame(scene.as_oracle(), view.as_dict(), hzb, d, cullingFlags=7, maxGroups=cap, record_capacity=cap))
+        # new meshlets: spheres moved and resized, cone words permuted
+        rng = np.random.default_rng(5)
+        ml2 = scene.meshlets.copy()
+        ml2["m_BoundingSphere"][:, :3] += rng.uniform(-0.3, 0.3, (len(ml2), 3)).astype(np.float32)
+        ml2["m_BoundingSphere"][:, 3] *= rng.uniform(0.5, 2.0, len(ml2)).astype(np.float32)
+        ml2["m_ConeAxisAndCutoff"] = rng.permutation(ml2["m_ConeAxisAndCutoff"])
+        half = (len(ml2) // 2)
+        gs.meshlets.upload(ml2[:half])                                        # first half: upload
+        pre = dev.create_command_list()                                       # second half: a write_buffer command executed in front of the frame
+        pre.open(); pre.write_buffer(gs.meshlets, ml2[half:], offset=half * ml2.dtype.itemsize); pre.close()
+        dev.execute(pre); pre.release()
+        scene2 = scene.as_oracle(); scene2["meshlets"] = ml2
+        hzb2 = _oracle_hzb(oracle, view, d)                                   # the HZB frame 1 left behind = built from d
+        drv.record(); drv.run()
+        _compare_frame(drv.results(), oracle.frame(scene2, view.as_dict(), hzb2, d, cullingFlags=7, maxGroups=cap, record_capacity=cap))
+    finally:
+        drv.release()
+        gs.release()
+
+
 @pytest.mark.parametrize("flags,mid_cap", [(7, False), (3, False), (7, True)])
 def test_instance_pass_continues_from_nonzero_counters(dev, oracle, flags, mid_cap):
     """gpuculling.hlsl:64-66, 165: the pass ADDS to whatever the group counter and the late counter hold.  Two dispatches

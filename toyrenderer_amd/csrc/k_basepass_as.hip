@@ -60,7 +60,7 @@ constexpr uint32_t kWaves = kBlock / 64;
 constexpr uint32_t kBatch = 64;                  // records per wave batch
 constexpr uint32_t kSteps = kBatch / 2;          // two records per wave step
 #ifndef TR_RING_SLOTS
-#define TR_RING_SLOTS 2      /* steps of MeshletData in flight per wave (2 KB each, staged in LDS) */
+#define TR_RING_SLOTS 2      /* steps of the meshlet cull stream in flight per wave (1.25 KB each, staged in LDS) */
 #endif
 #ifndef TR_CULL_BATCH
 /* records per wave and prologue: a multiple of 2 * TR_RING_SLOTS.  Measured on C3 with 2 ring slots: 64 records (47 KB of
@@ -89,6 +89,7 @@ static_assert(kCullSteps % kRingSlots == 0 && kCullBatch <= 64, "a batch is a wh
 #endif
 constexpr uint32_t kCullWaves = TR_CULL_WAVES;   // meshlet cull: waves per workgroup (= per window of 64 * kCullWaves... records)
 constexpr uint32_t kCullBlock = 64 * kCullWaves;
+constexpr uint32_t kSlotBytes = 1280;            // a ring slot: 64 spheres + 64 cone words (issueMeshletLoads)
 constexpr uint32_t kSlowCap = 32;                // per wave and batch: lookups deferred to the texel path (see OccQuad::slow)
 
 struct RecordInfo                                 // per-record invariants parked in LDS (96 B, read as 128-bit words)
@@ -257,7 +258,7 @@ __device__ __forceinline__ void issueMeshletLoads(char* slotLds /* wave-uniform 
 #define TR_LK_POLICY " sc1 nt"
 #endif
 #ifndef TR_CULL_WAVES_PER_EU
-#define TR_CULL_WAVES_PER_EU 4   /* waves per SIMD the register allocation aims at; LDS: 4 workgroups of 33.4 KB per CU (4, 5 and 6 per CU measured alike) */
+#define TR_CULL_WAVES_PER_EU 5   /* waves per SIMD the register allocation aims at (96 VGPRs; the full-flags table kernel spills five dwords outside its loop) = workgroups of 27.3 KB LDS per CU.  With the 32-byte records staged (rounds 2-3) 4, 5 and 6 per CU ran alike; with the 20-byte stream the kernel is closer to its issue time and 5 is 2.3 % faster than 4 */
 #endif
 template <bool FRUSTUM, bool OCCLUSION, bool CONE, bool TABLE>
 __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullKernel(MeshletCullArgs a)
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
     __shared__ uint32_t s_slowAll[kCullWaves][kSlowCap];
     __shared__ uint32_t s_slowCount[kCullWaves];
     __shared__ __attribute__((aligned(8))) uint32_t s_maskAll[kCullWaves][kCullBatch + 2];   // [0], [1]: where the deferred resolve of "the step before the first" lands
-    __shared__ __attribute__((aligned(16))) char s_ring[kCullWaves][kRingSlots][2048];   // per wave: the ring slots of staged MeshletData
+    __shared__ __attribute__((aligned(16))) char s_ring[kCullWaves][kRingSlots][kSlotBytes];   // per wave: the ring slots of the staged meshlet cull stream
 
     const uint32_t G = groupCount(a);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
         };
         auto step = [&](auto kc, uint32_t s) {
             constexpr uint32_t kSlot = decltype(kc)::value, kPrev = (kSlot + kRingSlots - 1u) % kRingSlots;
-            char* const slot = ring + 2048u * kSlot;
+            char* const slot = ring + kSlotBytes * kSlot;
             TR_STAMP(7);   // loop overhead / previous tail
             const uint32_t r = 2 * s + half;                                         // record within the batch
             const RecordInfo& ri = s_rec[r];
@@ -584,12 +585,12 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
         // lands in s_mask[0], [1].
 #pragma unroll
         for (uint32_t k = 0; k + 1 < kRingSlots; ++k)
-            issueMeshletLoads(ring + 2048u * k, a.stream, s_rec[2 * (s0 + k) + half].first, s_rec[2 * (s0 + k) + half].lastOff, sub16);
+            issueMeshletLoads(ring + kSlotBytes * k, a.stream, s_rec[2 * (s0 + k) + half].first, s_rec[2 * (s0 + k) + half].lastOff, sub16);
         if (kDefer) {
             const void* p = TABLE ? (const void*)a.quad.base : (const void*)a.hzb.base;
             issueLookup(lk0[kRingSlots - 1u], lk1[kRingSlots - 1u], p, p, 0ull);
         }
-        issueMeshletLoads(ring + 2048u * (kRingSlots - 1u), a.stream, s_rec[2 * (s0 + kRingSlots - 1u) + half].first, s_rec[2 * (s0 + kRingSlots - 1u) + half].lastOff, sub16);
+        issueMeshletLoads(ring + kSlotBytes * (kRingSlots - 1u), a.stream, s_rec[2 * (s0 + kRingSlots - 1u) + half].first, s_rec[2 * (s0 + kRingSlots - 1u) + half].lastOff, sub16);
 #pragma unroll 1
         for (uint32_t s = s0; s < nSteps; s += kRingSlots) {
             step(std::integral_constant<uint32_t, 0>{}, s);
