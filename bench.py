@@ -326,9 +326,11 @@ def main():
         r0 = res[0]
         t0_tested = gs_num_meshlets(spec, r0["records"])
         inst_submitted = len(np.unique(r0["records"]["m_InstanceConstIdx"]))
-        # ALGORITHMIC bytes of one launch of the early meshlet-cull kernel (DESIGN.md "Kernels"):
+        # ALGORITHMIC bytes of one launch of the early meshlet-cull kernel (DESIGN.md "Kernels", SURVEY 8(d)):
         # 32 B MeshletData per meshlet tested + 12 B record read + 4 B mask written per group
-        # + 68 B (world matrix + mesh index) per submitted instance
+        # + 68 B (world matrix + mesh index) per submitted instance.  The kernel itself streams a derived 20-byte copy of
+        # what it needs of each MeshletData (the meshlet cull stream), so `traffic` is BELOW this figure: `frac` prices the
+        # reference's bytes against the kernel's time as the contract asks; `frac_by_traffic` prices the bytes that moved.
         alg_bytes = 32 * t0_tested + 16 * len(r0["records"]) + 68 * inst_submitted
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, committed summary):
@@ -349,6 +351,7 @@ def main():
         frame_frac = frame_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS if world == 1 else None
         roofline = dict(bound="hbm", kernel=DOMINANT, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, avg_launch_ms=round(avg_ms, 4),
+                        frac_by_traffic=round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                         frame_frac=round(frame_frac, 4) if frame_frac is not None else None, frame_algorithmic_bytes=int(frame_alg),
                         # against what a streaming-read kernel reaches on this part (tools/membw.hip, profiles/r1/membw_calibration.txt)
                         frac_of_measured_stream=round(achieved / MEASURED_STREAM_GBS, 4), measured_stream_peak=MEASURED_STREAM_GBS,
