@@ -192,9 +192,9 @@ __device__ __forceinline__ void issueMeshletLoads(char* slotLds /* wave-uniform 
 #ifdef TR_EXP_NOMEM      /* experiment, results WRONG: every wave streams the same block (cache hits): the kernel without its HBM traffic */
     firstIdx &= 63u;
 #endif
-    const uint32_t o = min(sub16, lastOff) & ~15u;                                   // 16 * min(sub, count - 1): basepass.hlsl:65
-    const char* pa = reinterpret_cast<const char*>(stream.sphere) + (((uint64_t)firstIdx << 4) + o);
-    const char* pb = reinterpret_cast<const char*>(stream.cone) + (((uint64_t)firstIdx << 2) + (o >> 2));
+    const uint32_t idx = firstIdx + (min(sub16, lastOff) >> 4);                      // first + min(sub, count - 1): basepass.hlsl:65 (< numMeshlets <= 2^32)
+    const char* pa = reinterpret_cast<const char*>(stream.sphere) + ((uint64_t)idx << 4);
+    const char* pb = reinterpret_cast<const char*>(stream.cone) + ((uint64_t)idx << 2);
     const uint32_t ldsOff = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)slotLds;
     // nt: the 1.1 GB stream is read once and must not evict the HZB table and the per-record data from the L2s
 #ifndef TR_DMA_POLICY_ID
@@ -386,15 +386,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
         //      level of dependent loads here -- the entry itself was fetched while the previous batch ran ------
         {
             RecordInfo ri;
-            ri.lastOff = 0; ri.first = 0; ri.maxScale = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) ri.wxy[i] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ri.wz[i] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) ri.adjxy[i] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) ri.adjz[i] = 0.f;
+            ri.lastOff = 0; ri.first = 0;
             const uint4 cur = entry;
             entry = loadEntry(sbNext);                                               // next batch's entry: in flight during this batch
             const uint32_t g = cur.x < G && (lane >> 1) >= s0 && (lane >> 1) < nSteps ? cur.x : 0xFFFFFFFFu;
@@ -432,6 +424,16 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
                 if (base + cnt > a.numMeshlets) cnt = 0;                             // never read outside the meshlet buffer
                 ri.lastOff = lastOffOf(cnt);
                 if (cnt) ri.first = (uint32_t)base;                                  // < numMeshlets <= 2^32 (recordASMain)
+            } else if (lane < kCullBatch) {                                          // no record (past the list, or outside this team's piece): tests nothing
+                ri.maxScale = 0.f;                                                   // (zeroed here, not in front of the branch: full batches never come this way)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ri.wxy[i] = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ri.wz[i] = 0.f;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) ri.adjxy[i] = 0.f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) ri.adjz[i] = 0.f;
             }
             if (lane < kCullBatch) s_rec[lane] = ri;
         }
