@@ -352,6 +352,9 @@ def main():
         roofline = dict(bound="hbm", kernel=DOMINANT, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, avg_launch_ms=round(avg_ms, 4),
                         frac_by_traffic=round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                        note="frac prices the reference's bytes (32 B MeshletData per meshlet) against the kernel's time; the kernel streams a derived "
+                             "20-byte copy (traffic, frac_by_traffic) and is bound by instruction issue: VALU active 0.80-0.82, within 6 % of its "
+                             "no-memory time (profiles/r3/experiments.md section 12)",
                         frame_frac=round(frame_frac, 4) if frame_frac is not None else None, frame_algorithmic_bytes=int(frame_alg),
                         # against what a streaming-read kernel reaches on this part (tools/membw.hip, profiles/r1/membw_calibration.txt)
                         frac_of_measured_stream=round(achieved / MEASURED_STREAM_GBS, 4), measured_stream_peak=MEASURED_STREAM_GBS,
