@@ -429,6 +429,7 @@ int trhip_buffer_bind_memory(trhip_buffer buf, trhip_heap heap, uint64_t offset)
     heapRetain(heap);
     buf->heap = heap;
     buf->ptr = (char*)heap->base + offset;
+    buf->version.fetch_add(1);                      // other memory = other contents: derived data (cull cache, meshlet cull stream) is stale
     return TRHIP_OK;
 }
 
@@ -495,6 +496,7 @@ int trhip_texture_bind_memory(trhip_texture t, trhip_heap heap, uint64_t offset)
     heapRetain(heap);
     t->heap = heap;
     t->ptr = (char*)heap->base + offset;
+    t->version.fetch_add(1);                        // other memory = other contents: the footprint-min table is stale
     return TRHIP_OK;
 }
 
