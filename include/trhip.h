@@ -126,6 +126,17 @@ int  trhip_buffer_download(trhip_buffer buf, uint64_t src_offset, void* dst, uin
 int  trhip_texture_upload(trhip_texture tex, uint32_t mip, const void* src, uint64_t bytes);
 int  trhip_texture_download(trhip_texture tex, uint32_t mip, void* dst, uint64_t bytes);
 
+/* Contents changed behind the back end's back.  The back end keeps derived, private copies of some bound resources (the
+ * instance cull cache, the meshlet cull stream of the buffer bound at t4 of basepass_AS_Main, an HZB's footprint-min table)
+ * and rebuilds them when the source's version counter moves.  The counter moves for every write the back end SEES:
+ * trhip_*_upload, a UAV use in an executed command list, trhip_*_bind_memory.  A write it cannot see -- through the raw
+ * pointer of trhip_buffer_wrap / trhip_*_device_ptr (a torch kernel, hipMemcpy), through a second wrap of the same memory,
+ * through another virtual resource aliased on the same heap range -- MUST be followed by this call (any thread; ordered by
+ * the caller before the next trhip_queue_execute that reads the resource), or later culls use the old contents.
+ * nvrhi has no counterpart: D3D12 shaders read the buffers themselves. */
+int  trhip_buffer_mark_written(trhip_buffer buf);
+int  trhip_texture_mark_written(trhip_texture tex);
+
 /* ---- command lists: replaces nvrhi::ICommandList (Graphic.cpp:520-606,893-947) --------------- */
 typedef enum {
     TRHIP_BIND_CONSTANT_BUFFER = 0,  /* nvrhi::BindingSetItem::ConstantBuffer(slot, buf)        */
@@ -194,6 +205,9 @@ int  trhip_timer_get_ms(trhip_timer t, float* ms);   /* waits for the end event 
  * When enabled, every dispatch executed is bracketed by HIP events on the device stream and
  * accumulated under its shader name (sub-kernels under "name#kernel").  Off by default. */
 int  trhip_profile_enable(trhip_device dev, int enabled);
+/* Bracket only the dispatches accumulated under exactly `name` ("shader#kernel"); NULL or "" = all of them.  One event pair
+ * per frame instead of one per launch: the frame keeps its steady-state overlap and clocks while one kernel is timed. */
+int  trhip_profile_filter(trhip_device dev, const char* name);
 int  trhip_profile_reset(trhip_device dev);
 int  trhip_profile_count(trhip_device dev, uint32_t* n);
 int  trhip_profile_entry(trhip_device dev, uint32_t index, const char** name, uint64_t* launches, double* total_ms);

@@ -485,6 +485,53 @@ def test_meshlet_buffer_rewritten_between_frames(dev, oracle, table):
         gs.release()
 
 
+@pytest.mark.parametrize("table", [False, True])
+def test_meshlet_and_instance_buffers_written_out_of_band_then_marked(dev, oracle, table):
+    """a write the back end cannot see -- here through a SECOND wrap of the same device memory, as a torch kernel or
+    a hipMemcpy on the raw pointer would -- leaves the derived copies (meshlet cull stream, instance cull cache) stale until
+    trhip_buffer_mark_written is called on the bound buffer (include/trhip.h).  After the call the next frame follows the
+    new contents word for word."""
+    from toyrenderer_amd.frame import FrameDriver, GpuScene
+    view = synth.make_view(eye=(0.1, 0.2, 0.3), yaw=-0.02, render=(640, 360))
+    spec = synth.SceneSpec(num_meshes=24, num_instances=400, meshlets_lod0=66, jitter_meshlets=True, max_lods=2, seed=717)
+    scene = synth.make_scene(spec)
+    d = synth.gen_depth(view, num_occluders=40, seed=3, scale=3.0)
+    hzb = _oracle_hzb(oracle, view, d)
+    gs = GpuScene(dev, scene.instances, scene.meshData, scene.meshlets, scene.opaqueIds, scene.alphaMaskIds)
+    cap = (1 << 19) if table else 65535
+    drv = FrameDriver(dev, gs, view, record_capacity=cap, culling_flags=7)
+    _upload_hzb(drv, hzb)
+    drv.depth.upload_mip(0, d)
+    alias_m = alias_i = None
+    try:
+        drv.record(); drv.run()
+        _compare_frame(drv.results(), oracle.frame(scene.as_oracle(), view.as_dict(), hzb, d, cullingFlags=7, maxGroups=cap, record_capacity=cap))
+        rng = np.random.default_rng(11)
+        ml2 = scene.meshlets.copy()
+        ml2["m_BoundingSphere"][:, :3] += rng.uniform(-0.4, 0.4, (len(ml2), 3)).astype(np.float32)
+        ml2["m_BoundingSphere"][:, 3] *= rng.uniform(0.5, 1.5, len(ml2)).astype(np.float32)
+        ml2["m_ConeAxisAndCutoff"] = rng.permutation(ml2["m_ConeAxisAndCutoff"])
+        inst2 = scene.instances.copy()
+        inst2["m_WorldMatrix"][:, 3, :3] += rng.uniform(-0.5, 0.5, (len(inst2), 3)).astype(np.float32)
+        # out of band: another handle on the same memory
+        alias_m = dev.wrap_buffer(gs.meshlets.ptr, ml2.nbytes, name="meshlets alias", stride=ml2.dtype.itemsize)
+        alias_i = dev.wrap_buffer(gs.instances.ptr, inst2.nbytes, name="instances alias", stride=inst2.dtype.itemsize)
+        alias_m.upload(ml2)
+        alias_i.upload(inst2)
+        gs.meshlets.mark_written()
+        gs.instances.mark_written()
+        scene2 = scene.as_oracle(); scene2["meshlets"] = ml2; scene2["instances"] = inst2
+        hzb2 = _oracle_hzb(oracle, view, d)
+        drv.record(); drv.run()
+        _compare_frame(drv.results(), oracle.frame(scene2, view.as_dict(), hzb2, d, cullingFlags=7, maxGroups=cap, record_capacity=cap))
+    finally:
+        for b in (alias_m, alias_i):
+            if b is not None:
+                b.release()
+        drv.release()
+        gs.release()
+
+
 @pytest.mark.parametrize("flags,mid_cap", [(7, False), (3, False), (7, True)])
 def test_instance_pass_continues_from_nonzero_counters(dev, oracle, flags, mid_cap):
     """gpuculling.hlsl:64-66, 165: the pass ADDS to whatever the group counter and the late counter hold.  Two dispatches

@@ -476,13 +476,17 @@ __device__ __forceinline__ F3 coneAxisCutoff(uint32_t packed, float* cutoff)
     return { a01.x, a01.y, fma_(q23.x, 2.0f, -1.0f) };
 }
 
-// The same through a 256-entry table in LDS, entry x = { fma(x / 255, 2, -1), x / 255 } computed with the arithmetic above
-// (coneTableEntry): four byte-indexed reads instead of 4 conversions + 7 packed operations per meshlet.
-__device__ __forceinline__ float2 coneTableEntry(uint32_t x) { const float q = u8Unorm(x); return make_float2(fma_(q, 2.0f, -1.0f), q); }
-__device__ __forceinline__ F3 coneAxisCutoffLds(uint32_t packed, float* cutoff, const float2* tab)
+// The same through two 256-entry tables in LDS computed with the arithmetic above: tab[x] = fma(x / 255, 2, -1) (axis component),
+// tab[256 + x] = x / 255 (cutoff): four byte-indexed reads instead of 4 conversions + 7 packed operations per meshlet.
+// Two dense float tables, not one of {axis, cutoff} pairs: the byte-indexed ds_read_b32 of 64 lanes then spread over all 32
+// LDS banks instead of the 16 even (axis) or 16 odd (cutoff) ones (round 3: SQ_LDS_BANK_CONFLICT 28.0 M cycles per launch
+// against 18.6 M LDS-active ones; profiles/r4/experiments.md).
+constexpr uint32_t kConeTabEntries = 512;
+__device__ __forceinline__ float coneTableEntry(uint32_t i) { const float q = u8Unorm(i & 0xFFu); return i < 256u ? fma_(q, 2.0f, -1.0f) : q; }
+__device__ __forceinline__ F3 coneAxisCutoffLds(uint32_t packed, float* cutoff, const float* tab)
 {
-    *cutoff = tab[packed >> 24].y;
-    return { tab[packed & 0xFFu].x, tab[(packed >> 8) & 0xFFu].x, tab[(packed >> 16) & 0xFFu].x };
+    *cutoff = tab[256u + (packed >> 24)];
+    return { tab[packed & 0xFFu], tab[(packed >> 8) & 0xFFu], tab[(packed >> 16) & 0xFFu] };
 }
 
 #ifdef TR_COUNT_PATHS
@@ -493,7 +497,7 @@ __device__ __forceinline__ F3 coneAxisCutoffLds(uint32_t packed, float* cutoff, 
 
 template <bool OCC, bool CONE, bool CONETAB = false>
 __device__ __forceinline__ void stepQuotients(lmask active, F3 c, float r, uint32_t packed, const M33P& adj, float nearPlane, bool nearInRange, StepQuot& o,
-                                              const float2* coneTab = nullptr /* CONETAB: LDS, coneTableEntry() per byte value */)
+                                              const float* coneTab = nullptr /* CONETAB: LDS, coneTableEntry(i), i < kConeTabEntries */)
 {
     // active: the lane tests a meshlet.  The others (past the end of a record, records past the end of the list) run along
     // on whatever operands they hold, never reach an output and must not send the wave down the EXACT path.

@@ -227,6 +227,8 @@ void ShardExchangeCreate(const trhost_exchange_desc& d)
             x.masks[s] = makeBuffer(x.commDev, 4ull * groupCap, "AllMasks");
             x.list[s] = makeBuffer(x.commDev, 4ull * listCap, "AllVisibleList");
             x.args[s] = makeBuffer(x.commDev, 32, "AllArgs");
+            const uint32_t zeros[8] = {};                                       // word 7 = status: read by ShardExchangeWait before any run wrote it
+            require(trhip_buffer_upload(x.args[s], 0, zeros, sizeof zeros), "exchange: zero the argument words");
         }
     {   // visibility_CS_PackShard's state words (two halves): zero once, every launch zeroes the half the next one uses
         const uint64_t words = 2ull * (d.slot_groups / 1024u + kMaxPassSlots + 1u);
@@ -266,6 +268,7 @@ void ShardExchangeWait()
     // A slot that overflowed, a corrupt header, a whole-scene buffer too small, a rank that dropped groups at its capacity
     // without a global capacity to cut at: the unpack flags them in word 7 of the pass slot's arguments (gather.py STATUS_*).
     // Such a frame must not be consumed silently.
+    if (g_Exchange->frame == 0) return;                                      // nothing has run: nothing to check
     for (uint32_t s = 0; s < kMaxPassSlots; ++s) {
         if (!g_Exchange->wants(s) || !g_Exchange->args[s]) continue;
         uint32_t status = 0;

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
     __shared__ uint32_t s_gIdxAll[kCullWaves][kCullBatch];
     __shared__ uint32_t s_quadOff[16];                 // texel path: mip offsets
     __shared__ uint4 s_mipTab[17];                     // table path: per-mip constants indexed by exponent + 1 (cm::occTailQuad)
-    __shared__ float2 s_coneTab[256];                  // cone byte -> { axis component, cutoff } (cm::coneTableEntry)
+    __shared__ float s_coneTab[cm::kConeTabEntries];   // cone byte -> axis component [0, 256), cutoff [256, 512) (cm::coneTableEntry)
     __shared__ uint32_t s_slowAll[kCullWaves][kSlowCap];
     __shared__ uint32_t s_slowCount[kCullWaves];
     __shared__ __attribute__((aligned(8))) uint32_t s_maskAll[kCullWaves][kCullBatch + 2];   // [0], [1]: where the deferred resolve of "the step before the first" lands
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
     }
     // the fast arithmetic path wants nearPlane in [2^-20, 2^20] (cm::stepQuotients)
     const bool nearInRange = a.k.m_NearPlane >= 0x1p-20f && a.k.m_NearPlane <= 0x1p20f;
-    if (CONE) s_coneTab[tid] = cm::coneTableEntry(tid);
+    if (CONE) for (uint32_t i = tid; i < cm::kConeTabEntries; i += kCullBlock) s_coneTab[i] = cm::coneTableEntry(i);   // (any workgroup size: TR_CULL_WAVES)
     if (tid < kCullWaves) s_slowCount[tid] = 0;
     if (lane < 2 * kRingSlots) { s_recAll[wave][kCullBatch + lane].first = 0; s_recAll[wave][kCullBatch + lane].lastOff = 0; }
     uint32_t* s_slow = s_slowAll[wave];
@@ -1456,6 +1456,11 @@ int recordASMain(trhip::DispatchCtx& ctx)
     const bool table = useTable;
     if (quadOwner) ctx.cl->use(quadOwner->quad, ctx.cl->ops.size(), false);     // the kernel reads the table: ordered after a side-stream rebuild
     ctx.emit("cull", [a, grid, flags, quadOwner, table, instances, meshData, meshlets](hipStream_t s) {
+        // A virtual buffer bound to other memory after this list was recorded (trhip_buffer_bind_memory): the recorded pointers
+        // are the old memory's, the derived stream would be built from the new one.  nvrhi rebuilds binding sets on such a
+        // change; here the list must be recorded again.
+        if ((const void*)a.meshlets != meshlets->ptr)
+            return trhip::fail(TRHIP_ERR_STATE, "basepass_AS_Main: the meshlet buffer was bound to other memory after this command list was recorded: record it again");
         {                                                  // no-op unless the instance or mesh buffer was written since the cache was built
             int crc = trhip::instanceCacheLaunchBuild(instances, meshData, s);
             if (crc != TRHIP_OK) return crc;

@@ -544,6 +544,20 @@ int trhip_buffer_upload(trhip_buffer b, uint64_t off, const void* src, uint64_t 
     return rc;
 }
 
+int trhip_buffer_mark_written(trhip_buffer b)
+{
+    if (!b) return fail(TRHIP_ERR_INVALID, "buffer_mark_written: null argument");
+    b->version.fetch_add(1);                   // derived data (instance cull cache, meshlet cull stream) is rebuilt by the next pass that wants it
+    return TRHIP_OK;
+}
+
+int trhip_texture_mark_written(trhip_texture t)
+{
+    if (!t) return fail(TRHIP_ERR_INVALID, "texture_mark_written: null argument");
+    t->version.fetch_add(1);                   // the footprint-min table is rebuilt by the next pass that wants it
+    return TRHIP_OK;
+}
+
 int trhip_buffer_download(trhip_buffer b, uint64_t off, void* dst, uint64_t bytes)
 {
     if (!b || !dst) return fail(TRHIP_ERR_INVALID, "buffer_download: null argument");
@@ -865,7 +879,7 @@ int trhip_queue_execute(trhip_device dev, const trhip_cmdlist* lists, uint32_t n
                     if (m.write && m.version) m.version->fetch_add(1);     // the contents change with this command
                 }
             }
-            const bool prof = dev->profiling && !op.name.empty();
+            const bool prof = dev->profiling && !op.name.empty() && (dev->profileFilter.empty() || dev->profileFilter == op.name);
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (prof) { e0 = dev->acquireEvent(); e1 = dev->acquireEvent(); TRHIP_HIP(hipEventRecord(e0, stream)); }
             const auto h0 = g_hostProfile.on ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point{};
@@ -968,6 +982,14 @@ int trhip_profile_enable(trhip_device dev, int enabled)
     if (!dev) return fail(TRHIP_ERR_INVALID, "device is null");
     std::lock_guard<std::mutex> lock(dev->mutex);
     dev->profiling = enabled != 0;
+    return TRHIP_OK;
+}
+
+int trhip_profile_filter(trhip_device dev, const char* name)
+{
+    if (!dev) return fail(TRHIP_ERR_INVALID, "device is null");
+    std::lock_guard<std::mutex> lock(dev->mutex);
+    dev->profileFilter = name ? name : "";
     return TRHIP_OK;
 }
 

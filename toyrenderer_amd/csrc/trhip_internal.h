@@ -67,6 +67,7 @@ struct trhip_device_t
 
     std::mutex mutex;
     bool profiling = false;
+    std::string profileFilter;              // "" = every named op; else only ops of exactly this name (trhip_profile_filter)
     std::vector<trhip::ProfilePending> pending;
     std::vector<hipEvent_t> eventPool;
     std::map<std::string, trhip::ProfileAccum> accum;

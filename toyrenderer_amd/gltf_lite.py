@@ -334,7 +334,7 @@ def build_lod_chain(positions: np.ndarray, indices: np.ndarray, simplifier=simpl
     error = accumulated relative error * simplify_scale (the value MeshLODData::m_Error carries, :345)."""
     # :336-338: the reference's constants are FLOATs (0.65f, 0.85f) multiplied into double(size): 60 indices -> 38.99999
     # -> 38 -> target 36 (with the double 0.65 it would be 39 -> 39)
-    kTargetError = 0.1
+    kTargetError = float(np.float32(0.1))                                                         # :334 0.1f
     kTargetIndexCountPercentage, kMinIndexReductionPercentage = float(np.float32(0.65)), float(np.float32(0.85))
     scale = np.float32(simplify_scale(positions))                                                 # :324
     lod_indices = np.asarray(indices, np.uint32).copy()

@@ -29,12 +29,13 @@ ABI_SYMBOLS = [
     "trhip_texture_create", "trhip_texture_memory_requirements", "trhip_texture_bind_memory", "trhip_texture_retain",
     "trhip_texture_release", "trhip_texture_device_ptr", "trhip_texture_mip_info", "trhip_texture_size",
     "trhip_buffer_upload", "trhip_buffer_download", "trhip_texture_upload", "trhip_texture_download",
+    "trhip_buffer_mark_written", "trhip_texture_mark_written",
     "trhip_cmd_create", "trhip_cmd_release", "trhip_cmd_open", "trhip_cmd_close", "trhip_cmd_write_buffer",
     "trhip_cmd_clear_buffer_u32", "trhip_cmd_clear_texture_f32", "trhip_cmd_copy_buffer", "trhip_cmd_copy_texture", "trhip_cmd_host_callback", "trhip_cmd_dispatch", "trhip_cmd_dispatch_indirect",
     "trhip_cmd_begin_timer", "trhip_cmd_end_timer", "trhip_cmd_begin_marker", "trhip_cmd_end_marker",
     "trhip_queue_execute",
     "trhip_timer_create", "trhip_timer_release", "trhip_timer_get_ms",
-    "trhip_profile_enable", "trhip_profile_reset", "trhip_profile_count", "trhip_profile_entry",
+    "trhip_profile_enable", "trhip_profile_filter", "trhip_profile_reset", "trhip_profile_count", "trhip_profile_entry",
     "trhip_launch_shard_late_info",
     "trhip_stream_create", "trhip_stream_create_priority", "trhip_stream_destroy", "trhip_stream_synchronize", "trhip_event_create", "trhip_event_destroy",
     "trhip_event_record", "trhip_stream_wait_event",
@@ -147,7 +148,10 @@ def load() -> C.CDLL:
     L.trhip_timer_create.argtypes = [vp, C.POINTER(vp)]
     L.trhip_timer_get_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.trhip_profile_enable.argtypes = [vp, i32]
+    L.trhip_profile_filter.argtypes = [vp, C.c_char_p]
     L.trhip_profile_reset.argtypes = [vp]
+    L.trhip_buffer_mark_written.argtypes = [vp]
+    L.trhip_texture_mark_written.argtypes = [vp]
     L.trhip_profile_count.argtypes = [vp, C.POINTER(u32)]
     L.trhip_profile_entry.argtypes = [vp, u32, C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(C.c_double)]
     _lib = L
@@ -185,6 +189,11 @@ class Buffer:
     def ptr(self) -> int:
         return load().trhip_buffer_device_ptr(self.h) or 0
 
+    def mark_written(self):
+        """The memory was written behind the back end's back (raw pointer, another wrap, an aliased resource): derived data
+        (instance cull cache, meshlet cull stream) must be rebuilt.  include/trhip.h: trhip_buffer_mark_written."""
+        _check(load().trhip_buffer_mark_written(self.h))
+
     def release(self):
         if self.h:
             load().trhip_buffer_release(self.h)
@@ -219,6 +228,10 @@ class Texture:
 
     def download_chain(self) -> np.ndarray:
         return np.concatenate([self.download_mip(k).ravel() for k in range(self.mips)])
+
+    def mark_written(self):
+        """See Buffer.mark_written: the footprint-min table of an HZB written through its raw pointer is stale."""
+        _check(load().trhip_texture_mark_written(self.h))
 
     def release(self):
         if self.h:
@@ -389,6 +402,7 @@ class Device:
 
     def profile_enable(self, on: bool = True): _check(load().trhip_profile_enable(self.h, int(on)))
     def profile_reset(self): _check(load().trhip_profile_reset(self.h))
+    def profile_filter(self, name: str | None): _check(load().trhip_profile_filter(self.h, name.encode() if name else None))
 
     def profile(self) -> dict:
         n = C.c_uint32()
