@@ -156,6 +156,12 @@ struct MeshletCullArgs
     const uint4* perm;                            // {record index, instance, first meshlet, count} in processing order
     InstanceCullCache cache;                      // world matrix, max scale, LOD table per instance (instance_cache.hip.h)
     uint32_t numInstances;
+    // The group count the list build works on: written by the cull kernel (G of groupCount()), read by count / scan / expand /
+    // compact INSTEAD of the dispatch arguments.  The list build of a large pass runs on the side stream, past the end of the
+    // frame's main chain; the next frame starts by clearing the dispatch arguments (BasePassRenderers.cpp:322-332), and with
+    // the arguments as the list build's input that clear -- the head of the next frame's chain -- had to wait for it (a
+    // cross-stream join, exposed: ~20 us per frame on C3, profiles/r4/experiments.md section 2).
+    uint32_t* listGroups;
 };
 
 __device__ __forceinline__ uint32_t groupCount(const MeshletCullArgs& a)
@@ -163,6 +169,10 @@ __device__ __forceinline__ uint32_t groupCount(const MeshletCullArgs& a)
     uint32_t G = a.dispatchArgs[0];
     if (a.argsWords > 3 && a.dispatchArgs[3] < G) G = a.dispatchArgs[3];   // Q2: only the defined prefix
     return G < a.recordCapacity ? G : a.recordCapacity;
+}
+__device__ __forceinline__ uint32_t listGroupCount(const MeshletCullArgs& a)      // the list build's view of it (MeshletCullArgs::listGroups)
+{
+    return a.listGroups ? a.listGroups[0] : groupCount(a);
 }
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -281,6 +291,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
     const uint32_t G = groupCount(a);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t half = lane >> 5, sub = lane & 31u;
+    if (a.listGroups && blockIdx.x == 0 && tid == 0) a.listGroups[0] = G;           // the list build's input (see MeshletCullArgs::listGroups)
     const cm::M43 V = cm::loadM43(a.k.m_WorldToView);
     const cm::M43P VP = cm::packM43(V);
     const cm::M33P VR = cm::rot(VP);
@@ -695,7 +706,7 @@ constexpr uint32_t kCountWaves = kCountThreads / 64;
 __global__ __launch_bounds__(kCountThreads) void visCountKernel(MeshletCullArgs a)
 {
     __shared__ uint32_t s_part[kCountWaves];
-    const uint32_t G = groupCount(a);
+    const uint32_t G = listGroupCount(a);
     const uint32_t numBatches = (G + kBatch - 1) / kBatch;
     const uint32_t numSupers = (numBatches + kSuperBatches - 1) >> kSuperShift;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -742,7 +753,7 @@ __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v, uint32_t lane)
 __global__ __launch_bounds__(1024) void visSuperScanKernel(MeshletCullArgs a)
 {
     __shared__ uint32_t s_wave[16];
-    const uint32_t G = groupCount(a);
+    const uint32_t G = listGroupCount(a);
     const uint32_t numBatches = (G + kBatch - 1) / kBatch;
     const uint32_t numSupers = (numBatches + kSuperBatches - 1) >> kSuperShift;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -769,7 +780,7 @@ __global__ __launch_bounds__(1024) void visSuperScanKernel(MeshletCullArgs a)
 __global__ __launch_bounds__(kBlock) void visExpandKernel(MeshletCullArgs a)
 {
     __shared__ uint2 s_mo[kWaves][kBatch];                    // per record of the wave's batch: {mask, list offset}
-    const uint32_t G = groupCount(a);
+    const uint32_t G = listGroupCount(a);
     const uint32_t numBatches = (G + kBatch - 1) / kBatch;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t half = lane >> 5, sub = lane & 31u;
@@ -832,7 +843,7 @@ __global__ __launch_bounds__(kCompactThreads) void visCompactKernel(MeshletCullA
     __shared__ uint32_t s_waveTot[kCompactWaves];
     __shared__ uint32_t s_tile;
     __shared__ unsigned long long s_pre[kCompactMaxTiles / 64u];
-    const uint32_t G = groupCount(a);
+    const uint32_t G = listGroupCount(a);
     const uint32_t numTiles = (G + kCompactTile - 1) / kCompactTile;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     for (;;) {
@@ -1249,7 +1260,7 @@ __global__ __launch_bounds__(256) void shardUnpackKernel(ShardUnpackArgs a)
 void emitListBuild(const trhip::DispatchCtx& ctx, const MeshletCullArgs& a, const char* prefix, bool side, const void* argsBase)
 {
     auto emit = [&](const std::string& name, std::function<int(hipStream_t)> fn) {
-        if (side) ctx.emitSide(name.c_str(), std::move(fn), { { argsBase, false }, { a.visMask, false }, { a.visibleList, true }, { a.drawArgs, true } });
+        if (side) ctx.emitSide(name.c_str(), std::move(fn), { { a.listGroups ? (const void*)a.listGroups : argsBase, false }, { a.visMask, false }, { a.visibleList, true }, { a.drawArgs, true } });
         else ctx.emit(name.c_str(), std::move(fn));
     };
     if (!side && a.recordCapacity <= kCompactMaxTiles * kCompactTile) {
@@ -1265,7 +1276,7 @@ void emitListBuild(const trhip::DispatchCtx& ctx, const MeshletCullArgs& a, cons
             if (grid > tiles) grid = tiles;
             if (grid == 0) grid = 1;
             emit(std::string(prefix) + "compact", [a, status, ticket, grid](hipStream_t s) {
-                hipLaunchKernelGGL(visCompactKernel, dim3(grid), dim3(kCompactThreads), 0, s, a, status, ticket);
+                TRHIP_LAUNCH(visCompactKernel, dim3(grid), dim3(kCompactThreads), 0, s, a, status, ticket);
                 return trhip::launchStatus("visCompactKernel"); });
             return;
         }
@@ -1281,21 +1292,21 @@ void emitListBuild(const trhip::DispatchCtx& ctx, const MeshletCullArgs& a, cons
     const std::string p = prefix;
     const uint32_t supers = (a.maxBatches >> kSuperShift) + 1u;
     emit(p + "count", [a, supers](hipStream_t s) {
-        hipLaunchKernelGGL(visCountKernel, dim3(supers), dim3(kCountThreads), 0, s, a);
+        TRHIP_LAUNCH(visCountKernel, dim3(supers), dim3(kCountThreads), 0, s, a);
         return trhip::launchStatus("visCountKernel"); });
     emit(p + "scan", [a](hipStream_t s) {
-        hipLaunchKernelGGL(visSuperScanKernel, dim3(1), dim3(1024), 0, s, a);
+        TRHIP_LAUNCH(visSuperScanKernel, dim3(1), dim3(1024), 0, s, a);
         return trhip::launchStatus("visSuperScanKernel"); });
     emit(p + "expand", [a, gridSmall](hipStream_t s) {
-        hipLaunchKernelGGL(visExpandKernel, dim3(gridSmall), dim3(kBlock), 0, s, a);
+        TRHIP_LAUNCH(visExpandKernel, dim3(gridSmall), dim3(kBlock), 0, s, a);
         return trhip::launchStatus("visExpandKernel"); });
 }
 
 template <bool F, bool O, bool C>
 void launchCull(const MeshletCullArgs& a, uint32_t grid, bool table, hipStream_t s)
 {
-    if (O && table) hipLaunchKernelGGL((meshletCullKernel<F, O, C, true>), dim3(grid), dim3(kCullBlock), 0, s, a);
-    else hipLaunchKernelGGL((meshletCullKernel<F, O, C, false>), dim3(grid), dim3(kCullBlock), 0, s, a);
+    if (O && table) TRHIP_LAUNCH((meshletCullKernel<F, O, C, true>), dim3(grid), dim3(kCullBlock), 0, s, a);
+    else TRHIP_LAUNCH((meshletCullKernel<F, O, C, false>), dim3(grid), dim3(kCullBlock), 0, s, a);
 }
 
 // ---- the meshlet cull stream (MeshletCullStream): layout, allocation, build ------------------------------------
@@ -1345,7 +1356,7 @@ int meshletStreamLaunchBuild(trhip_buffer_t* meshlets, hipStream_t s)
     if (meshlets->cullStreamVersion == v) return TRHIP_OK;
     const uint64_t n = meshlets->byteSize / sizeof(MeshletData);
     const uint64_t blocks = (n + 255u) / 256u;
-    hipLaunchKernelGGL(meshletStreamKernel, dim3((uint32_t)(blocks < 65536u ? (blocks ? blocks : 1u) : 65536u)), dim3(256), 0, s,
+    TRHIP_LAUNCH(meshletStreamKernel, dim3((uint32_t)(blocks < 65536u ? (blocks ? blocks : 1u) : 65536u)), dim3(256), 0, s,
                        (const MeshletData*)meshlets->ptr, n, meshletStreamLayout(meshlets->cullStream, n));
     meshlets->cullStreamVersion = v;
     return trhip::launchStatus("meshletStreamKernel");
@@ -1451,6 +1462,16 @@ int recordASMain(trhip::DispatchCtx& ctx)
     const uint32_t needBlocks = (a.recordCapacity + kCullBatch * kCullWaves - 1) / (kCullBatch * kCullWaves);
     if (grid > needBlocks) grid = needBlocks;
     if (grid == 0) grid = 1;
+    // the list build's group count: a word of back-end private memory that lives with the mask buffer (its sidecar): written by
+    // the cull on the main stream, read by the list build, possibly on the side stream -- the same address in every recording,
+    // so the hazard tracking orders the next frame's cull after this frame's list build through it
+    if (!visMask->sidecar) {
+        TRHIP_HIP(hipSetDevice(visMask->dev->index));
+        TRHIP_HIP(hipMalloc(&visMask->sidecar, 256));
+        visMask->sidecarBytes = 256;
+    }
+    a.listGroups = (uint32_t*)visMask->sidecar;
+    ctx.cl->use(a.listGroups, ctx.cl->ops.size(), true);
     const uint32_t flags = k->m_CullingFlags & 7u;
     trhip_texture_t* quadOwner = useTable ? hzb : nullptr;
     const bool table = useTable;
@@ -1546,7 +1567,7 @@ int recordPackShard(trhip::DispatchCtx& ctx)
         const uint32_t half = count->fetch_add(1u) & 1u;
         l.status = halves + (size_t)half * a.maxTiles;
         l.statusNext = halves + (size_t)(half ^ 1u) * a.maxTiles;
-        hipLaunchKernelGGL(shardPackKernel, dim3(grid), dim3(kPackThreads), 0, s, l);
+        TRHIP_LAUNCH(shardPackKernel, dim3(grid), dim3(kPackThreads), 0, s, l);
         return trhip::launchStatus("shardPackKernel"); });
     return TRHIP_OK;
 }
@@ -1610,7 +1631,7 @@ int recordUnpackShards(trhip::DispatchCtx& ctx)
     if (grid > need) grid = (uint32_t)need;
     if (grid == 0) grid = 1;
     ctx.emit("unpack", [a, grid](hipStream_t s) {
-        hipLaunchKernelGGL(shardUnpackKernel, dim3(grid), dim3(256), 0, s, a);
+        TRHIP_LAUNCH(shardUnpackKernel, dim3(grid), dim3(256), 0, s, a);
         return trhip::launchStatus("shardUnpackKernel"); });
     for (uint32_t s = 0; s < kMaxPassSlots; ++s)
         if (a.records[s]) {

@@ -161,7 +161,7 @@ int recordGIProbeCull(trhip::DispatchCtx& ctx)
     uint32_t grid = ctx.computeUnits() * 4u;
     if (grid > a.numTiles) grid = a.numTiles;
     ctx.emit("main", [a, grid](hipStream_t s) {
-        hipLaunchKernelGGL(giProbeCullKernel, dim3(grid), dim3(kProbeTile), 0, s, a);
+        TRHIP_LAUNCH(giProbeCullKernel, dim3(grid), dim3(kProbeTile), 0, s, a);
         return trhip::launchStatus("giProbeCullKernel"); });
     return TRHIP_OK;
 }

@@ -795,21 +795,21 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
         a.fusedStatus = (unsigned long long*)mem;
         a.fusedTicket = mem + (size_t)a.numBlocks * kFusedStatusStride * 2;
         ctx.emit("fused", [a](hipStream_t s) {
-            hipLaunchKernelGGL(instanceFusedKernel<LATE>, dim3(a.numBlocks), dim3(kBlock), 0, s, a);
+            TRHIP_LAUNCH(instanceFusedKernel<LATE>, dim3(a.numBlocks), dim3(kBlock), 0, s, a);
             return trhip::launchStatus("instanceFusedKernel"); });
         if (!LATE && occlusion) ctx.cl->peephole = { ctx.cl->ops.size() - 1, "gpuculling_early", std::make_shared<EarlyCullNote>(EarlyCullNote{ a, ctx.cl->ops.size() - 1, true }) };
         return TRHIP_OK;
     }
 
     ctx.emit("classify", [a](hipStream_t s) {
-        hipLaunchKernelGGL(instanceClassifyKernel<LATE>, dim3(a.numBlocks), dim3(kBigThreads), 0, s, a);
+        TRHIP_LAUNCH(instanceClassifyKernel<LATE>, dim3(a.numBlocks), dim3(kBigThreads), 0, s, a);
         return trhip::launchStatus("instanceClassifyKernel"); });
     ctx.emit("scan", [a](hipStream_t s) {
-        hipLaunchKernelGGL(instanceScanKernel<LATE>, dim3(1 + kScanTileGroups), dim3(kScanThreads), 0, s, a);
+        TRHIP_LAUNCH(instanceScanKernel<LATE>, dim3(1 + kScanTileGroups), dim3(kScanThreads), 0, s, a);
         return trhip::launchStatus("instanceScanKernel"); });
     const size_t scanOp = ctx.cl->ops.size() - 1;
     ctx.emit("emit", [a](hipStream_t s) {
-        hipLaunchKernelGGL(instanceEmitKernel<LATE>, dim3(a.numBlocks), dim3(kBigThreads), 0, s, a);
+        TRHIP_LAUNCH(instanceEmitKernel<LATE>, dim3(a.numBlocks), dim3(kBigThreads), 0, s, a);
         return trhip::launchStatus("instanceEmitKernel"); });
     if (!LATE && occlusion) ctx.cl->peephole = { ctx.cl->ops.size() - 1, "gpuculling_early", std::make_shared<EarlyCullNote>(EarlyCullNote{ a, scanOp, false }) };
     return TRHIP_OK;
@@ -836,10 +836,10 @@ int recordBuildLateArgs(trhip::DispatchCtx& ctx)
             const size_t scanOp = note->scanOp;
             if (note->fused)
                 ctx.cl->ops[scanOp].fn = [fused](hipStream_t s) {
-                    hipLaunchKernelGGL(instanceFusedKernel<0>, dim3(fused.numBlocks), dim3(kBlock), 0, s, fused);
+                    TRHIP_LAUNCH(instanceFusedKernel<0>, dim3(fused.numBlocks), dim3(kBlock), 0, s, fused);
                     return trhip::launchStatus("instanceFusedKernel"); };
             else ctx.cl->ops[scanOp].fn = [fused](hipStream_t s) {
-                hipLaunchKernelGGL(instanceScanKernel<0>, dim3(1 + kScanTileGroups), dim3(kScanThreads), 0, s, fused);
+                TRHIP_LAUNCH(instanceScanKernel<0>, dim3(1 + kScanTileGroups), dim3(kScanThreads), 0, s, fused);
                 return trhip::launchStatus("instanceScanKernel"); };
             // this dispatch's accesses (count read, arguments written) now happen in the scan command
             for (size_t i = ctx.cl->useMarks.size(); i-- > 0 && ctx.cl->useMarks[i].op >= ctx.cl->ops.size();) ctx.cl->useMarks[i].op = scanOp;
@@ -848,7 +848,7 @@ int recordBuildLateArgs(trhip::DispatchCtx& ctx)
         }
     }
     ctx.emit("main", [c, a](hipStream_t s) {
-        hipLaunchKernelGGL(buildLateCullIndirectArgsKernel, dim3(1), dim3(1), 0, s, c, a);
+        TRHIP_LAUNCH(buildLateCullIndirectArgsKernel, dim3(1), dim3(1), 0, s, c, a);
         return trhip::launchStatus("buildLateCullIndirectArgsKernel"); });
     return TRHIP_OK;
 }
@@ -887,7 +887,7 @@ int instanceCacheLaunchBuild(trhip_buffer_t* instances, trhip_buffer_t* meshData
     if (instances->cullCacheInstVersion == vi && instances->cullCacheMeshVersion == vm && instances->cullCacheMesh == meshData->ptr) return TRHIP_OK;
     const uint32_t n = (uint32_t)(instances->byteSize / sizeof(BasePassInstanceConstants));
     const uint64_t numMeshes = meshData->byteSize / sizeof(MeshData);
-    hipLaunchKernelGGL(instanceCacheKernel, dim3((n + 255u) / 256u), dim3(256), 0, s, (const BasePassInstanceConstants*)instances->ptr, n,
+    TRHIP_LAUNCH(instanceCacheKernel, dim3((n + 255u) / 256u), dim3(256), 0, s, (const BasePassInstanceConstants*)instances->ptr, n,
                        (const MeshData*)meshData->ptr, (uint32_t)(numMeshes > 0xFFFFFFFFull ? 0xFFFFFFFFull : numMeshes),
                        instanceCacheLayout(instances->cullCache, n));
     instances->cullCacheInstVersion = vi; instances->cullCacheMeshVersion = vm; instances->cullCacheMesh = meshData->ptr;
@@ -900,6 +900,6 @@ extern "C" int trhip_launch_shard_late_info(void* hip_stream, const uint32_t* ga
 {
     if (!gathered_counts || !info || world == 0 || rank >= world)
         return trhip::fail(TRHIP_ERR_INVALID, "launch_shard_late_info: bad arguments (world %u, rank %u)", world, rank);
-    hipLaunchKernelGGL(shardLateInfoKernel, dim3(1), dim3(1), 0, (hipStream_t)hip_stream, gathered_counts, world, rank, info);
+    TRHIP_LAUNCH(shardLateInfoKernel, dim3(1), dim3(1), 0, (hipStream_t)hip_stream, gathered_counts, world, rank, info);
     return trhip::launchStatus("shardLateInfoKernel");
 }

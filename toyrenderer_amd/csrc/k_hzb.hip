@@ -356,8 +356,8 @@ int recordMinMaxDownsample(trhip::DispatchCtx& ctx)
     const bool mx = k->m_bDownsampleMax != 0;
     ctx.emit("main", [=](hipStream_t s) {
         dim3 grid((ow + 31) / 32, (oh + 7) / 8);
-        if (mx) hipLaunchKernelGGL(minMaxDownsampleKernel<true>, grid, dim3(256), 0, s, depth, W, H, out, ow, oh);
-        else hipLaunchKernelGGL(minMaxDownsampleKernel<false>, grid, dim3(256), 0, s, depth, W, H, out, ow, oh);
+        if (mx) TRHIP_LAUNCH(minMaxDownsampleKernel<true>, grid, dim3(256), 0, s, depth, W, H, out, ow, oh);
+        else TRHIP_LAUNCH(minMaxDownsampleKernel<false>, grid, dim3(256), 0, s, depth, W, H, out, ow, oh);
         return trhip::launchStatus("minMaxDownsampleKernel"); });
     ctx.cl->peephole = { ctx.cl->ops.size() - 1, "minmaxdownsample", std::make_shared<MinMaxNote>(MinMaxNote{ depth, W, H, out, ow, oh, mx }) };
     return TRHIP_OK;
@@ -405,16 +405,16 @@ int recordSPD(trhip::DispatchCtx& ctx)
         ctx.cl->ops.pop_back();
         ctx.emit("depth_tile", [a, n, lastMip, mx](hipStream_t s) {
             dim3 grid(a.width / 64, a.height / 64);
-            if (mx) hipLaunchKernelGGL(hzbDepthTileKernel<true>, grid, dim3(256), 0, s, n.depth, n.W, n.H, a, lastMip);
-            else hipLaunchKernelGGL(hzbDepthTileKernel<false>, grid, dim3(256), 0, s, n.depth, n.W, n.H, a, lastMip);
+            if (mx) TRHIP_LAUNCH(hzbDepthTileKernel<true>, grid, dim3(256), 0, s, n.depth, n.W, n.H, a, lastMip);
+            else TRHIP_LAUNCH(hzbDepthTileKernel<false>, grid, dim3(256), 0, s, n.depth, n.W, n.H, a, lastMip);
             return trhip::launchStatus("hzbDepthTileKernel"); });
         first = lastMip;
     } else if (tiled) {
         const uint32_t lastMip = tex->mips - 1 < 6 ? tex->mips - 1 : 6;
         ctx.emit("tile", [a, lastMip, mx](hipStream_t s) {
             dim3 grid(a.width / 64, a.height / 64);
-            if (mx) hipLaunchKernelGGL(spdTileKernel<true>, grid, dim3(256), 0, s, a, lastMip);
-            else hipLaunchKernelGGL(spdTileKernel<false>, grid, dim3(256), 0, s, a, lastMip);
+            if (mx) TRHIP_LAUNCH(spdTileKernel<true>, grid, dim3(256), 0, s, a, lastMip);
+            else TRHIP_LAUNCH(spdTileKernel<false>, grid, dim3(256), 0, s, a, lastMip);
             return trhip::launchStatus("spdTileKernel"); });
         first = lastMip;
     }
@@ -422,15 +422,15 @@ int recordSPD(trhip::DispatchCtx& ctx)
         const uint32_t mip = first + 1;
         const uint32_t texels = tex->mipW(mip) * tex->mipH(mip);
         ctx.emit("mip", [a, mip, texels, mx](hipStream_t s) {
-            if (mx) hipLaunchKernelGGL(spdMipKernel<true>, dim3((texels + 255u) / 256u), dim3(256), 0, s, a, mip);
-            else hipLaunchKernelGGL(spdMipKernel<false>, dim3((texels + 255u) / 256u), dim3(256), 0, s, a, mip);
+            if (mx) TRHIP_LAUNCH(spdMipKernel<true>, dim3((texels + 255u) / 256u), dim3(256), 0, s, a, mip);
+            else TRHIP_LAUNCH(spdMipKernel<false>, dim3((texels + 255u) / 256u), dim3(256), 0, s, a, mip);
             return trhip::launchStatus("spdMipKernel"); });
         first = mip;
     }
     if (first + 1 < tex->mips) {
         ctx.emit("tail", [a, first, mx](hipStream_t s) {
-            if (mx) hipLaunchKernelGGL(spdTailKernel<true>, dim3(1), dim3(1024), 0, s, a, first);
-            else hipLaunchKernelGGL(spdTailKernel<false>, dim3(1), dim3(1024), 0, s, a, first);
+            if (mx) TRHIP_LAUNCH(spdTailKernel<true>, dim3(1), dim3(1024), 0, s, a, first);
+            else TRHIP_LAUNCH(spdTailKernel<false>, dim3(1), dim3(1024), 0, s, a, first);
             return trhip::launchStatus("spdTailKernel"); });
     }
     return TRHIP_OK;
@@ -466,7 +466,7 @@ int hzbQuadLaunchBuild(trhip_texture_t* tex, hipStream_t s)
     const uint64_t v = tex->version;                   // called while commands are submitted: every earlier write is counted
     if (tex->quadBuiltVersion == v) return TRHIP_OK;   // nothing wrote the HZB since the last build
     const QuadArgs a = quadArgs(tex);
-    hipLaunchKernelGGL(hzbQuadBuildKernel, dim3(a.firstStrip[a.mips]), dim3(256), 0, s, a);
+    TRHIP_LAUNCH(hzbQuadBuildKernel, dim3(a.firstStrip[a.mips]), dim3(256), 0, s, a);
     tex->quadBuiltVersion = v;
     return launchStatus("hzbQuadBuildKernel");
 }

@@ -353,12 +353,12 @@ int recordRasterDepth(trhip::DispatchCtx& ctx)
     if (rc != TRHIP_OK) return rc;
     const uint32_t grid = ctx.computeUnits() * 4u;
     ctx.emit("main", [a, grid](hipStream_t s) {
-        hipLaunchKernelGGL(rasterDepthKernel, dim3(grid), dim3(kBlock), 0, s, a);
+        TRHIP_LAUNCH(rasterDepthKernel, dim3(grid), dim3(kBlock), 0, s, a);
         return trhip::launchStatus("rasterDepthKernel"); });
     const uint32_t tiles = ((a.width + kTile - 1) / kTile) * ((a.height + kTile - 1) / kTile);
     const uint32_t tileGrid = tiles < ctx.computeUnits() * 8u ? tiles : ctx.computeUnits() * 8u;
     ctx.emit("tiles", [a, tileGrid](hipStream_t s) {
-        hipLaunchKernelGGL(rasterTilesKernel, dim3(tileGrid), dim3(kBlock), 0, s, a);
+        TRHIP_LAUNCH(rasterTilesKernel, dim3(tileGrid), dim3(kBlock), 0, s, a);
         return trhip::launchStatus("rasterTilesKernel"); });
     return TRHIP_OK;
 }

@@ -173,7 +173,7 @@ int recordUpdateInstanceConsts(trhip::DispatchCtx& ctx)
                              instances->cullCacheBytes >= (instances->byteSize / sizeof(BasePassInstanceConstants)) * kInstanceCacheBytesPerInstance &&
                              !getenv("TRHIP_NO_CACHE_REFRESH");
         const InstanceCullCache cache = refresh ? instanceCacheLayout(instances->cullCache, instances->byteSize / sizeof(BasePassInstanceConstants)) : InstanceCullCache{};
-        hipLaunchKernelGGL(updateInstanceConstsKernel, dim3((n + kUpdBlock - 1) / kUpdBlock), dim3(kUpdBlock), 0, s, np, numNodes, pn, ip, n, refresh, cache);
+        TRHIP_LAUNCH(updateInstanceConstsKernel, dim3((n + kUpdBlock - 1) / kUpdBlock), dim3(kUpdBlock), 0, s, np, numNodes, pn, ip, n, refresh, cache);
         if (refresh) instances->cullCacheInstVersion = now;
         return trhip::launchStatus("updateInstanceConstsKernel"); });
     return TRHIP_OK;

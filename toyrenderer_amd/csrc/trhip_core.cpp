@@ -127,6 +127,8 @@ struct HostProfile
 }
 
 // ------------------------------------------------------------------------------------------------
+thread_local trhip::LaunchTap* trhip::g_launchTap = nullptr;
+
 hipEvent_t trhip_device_t::acquireEvent()
 {
     if (!eventPool.empty()) { hipEvent_t e = eventPool.back(); eventPool.pop_back(); return e; }
@@ -230,7 +232,7 @@ int trhip_cmdlist_t::recordClearWords(void* ptr, uint64_t words, uint32_t value,
             uint64_t grid = (most + 1023u) / 1024u;                      // ~4 words per thread for the largest range
             if (grid > (uint64_t)cus * 8u) grid = (uint64_t)cus * 8u;
             if (grid == 0) grid = 1;
-            hipLaunchKernelGGL(multiClearKernel, dim3((uint32_t)grid), dim3(256), 0, s, a);
+            TRHIP_LAUNCH(multiClearKernel, dim3((uint32_t)grid), dim3(256), 0, s, a);
             return trhip::launchStatus("multiClearKernel"); } });
         ops.back().kind = "clear_buffer";
         openClearOp = ops.size() - 1;
@@ -836,7 +838,7 @@ int trhip_queue_execute(trhip_device dev, const trhip_cmdlist* lists, uint32_t n
         runTouched.clear();
         return TRHIP_OK;
     };
-    auto waitForOwner = [&](const void* ptr, bool write) -> int {   // a main-stream command reads / writes `ptr`
+    auto ownerOf = [&](const void* ptr, bool write) -> uint64_t {   // a main-stream command reads / writes `ptr`: the side run it must follow
         uint64_t need = 0;                             // read after side write; write after side write or read
         auto w = dev->sideWriter.find(ptr);
         if (w != dev->sideWriter.end()) need = w->second;
@@ -844,10 +846,20 @@ int trhip_queue_execute(trhip_device dev, const trhip_cmdlist* lists, uint32_t n
             auto r = dev->sideReader.find(ptr);
             if (r != dev->sideReader.end() && r->second > need) need = r->second;
         }
+        return need;
+    };
+    auto waitForRun = [&](uint64_t need) -> int {
         if (need <= dev->mainWaitedUpTo) return TRHIP_OK;
         TRHIP_HIP(hipStreamWaitEvent(dev->stream, dev->runDone[need % trhip_device_t::kSideRuns], 0));
         dev->mainWaitedUpTo = need;                    // the side stream is in order: earlier runs are covered too
         return TRHIP_OK;
+    };
+    static const bool g_tapForks = getenv("TRHIP_NO_FORK_TAP") == nullptr;       // experiments: forks by marker packets, as in rounds 1-3
+    auto nextIsSide = [&](uint32_t li, size_t oi) -> bool {                       // the command after (li, oi), across list boundaries
+        if (!dev->sideStream) return false;
+        for (++oi; li < n; ++li, oi = 0)
+            if (lists[li] && oi < lists[li]->ops.size()) return lists[li]->ops[oi].lane == 1;
+        return false;
     };
     for (uint32_t i = 0; i < n; ++i) {
         trhip_cmdlist_t* cl = lists[i];
@@ -861,7 +873,8 @@ int trhip_queue_execute(trhip_device dev, const trhip_cmdlist* lists, uint32_t n
             hipStream_t stream = dev->stream;
             if (side) {
                 if (!inRun) {                          // fork: the side stream continues from this point of the main stream
-                    TRHIP_HIP(hipEventRecord(dev->evFork, dev->stream));
+                    if (!dev->forkSignalled) TRHIP_HIP(hipEventRecord(dev->evFork, dev->stream));   // (else: the last kernel's completion signal, LaunchTap)
+                    dev->forkSignalled = false;
                     TRHIP_HIP(hipStreamWaitEvent(dev->sideStream, dev->evFork, 0));
                     inRun = true;
                 }
@@ -872,18 +885,29 @@ int trhip_queue_execute(trhip_device dev, const trhip_cmdlist* lists, uint32_t n
             } else {
                 int rc = endRun();
                 if (rc != TRHIP_OK) return rc;
+                // ONE wait for the latest run any of the command's resources needs (a wait is a packet in the main queue: ~4 us
+                // of the frame's chain even when it is satisfied on arrival, tools/sync_cost.hip)
+                uint64_t need = 0;
                 for (; mark < cl->useMarks.size() && cl->useMarks[mark].op <= oi; ++mark) {
                     const trhip_cmdlist_t::UseMark& m = cl->useMarks[mark];
-                    rc = waitForOwner(m.ptr, m.write);
-                    if (rc != TRHIP_OK) return rc;
+                    need = std::max(need, ownerOf(m.ptr, m.write));
                     if (m.write && m.version) m.version->fetch_add(1);     // the contents change with this command
                 }
+                rc = waitForRun(need);
+                if (rc != TRHIP_OK) return rc;
             }
             const bool prof = dev->profiling && !op.name.empty() && (dev->profileFilter.empty() || dev->profileFilter == op.name);
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (prof) { e0 = dev->acquireEvent(); e1 = dev->acquireEvent(); TRHIP_HIP(hipEventRecord(e0, stream)); }
             const auto h0 = g_hostProfile.on ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point{};
+            // the next command forks the side stream from here: let this command's kernel carry the fork event (LaunchTap)
+            trhip::LaunchTap tap;
+            dev->forkSignalled = false;
+            const bool tapped = !side && !prof && g_tapForks && nextIsSide(i, oi);
+            if (tapped) { tap.onStream = stream; tap.stopEvent = dev->evFork; trhip::g_launchTap = &tap; }
             int rc = op.fn(stream);
+            trhip::g_launchTap = nullptr;
+            if (tapped && tap.launches == 1 && rc == TRHIP_OK) dev->forkSignalled = true;
             if (g_hostProfile.on) g_hostProfile.add(op.kind, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count());
             if (rc != TRHIP_OK) return rc;
             if (prof) { TRHIP_HIP(hipEventRecord(e1, stream)); dev->pending.push_back({ op.name, e0, e1 }); }

@@ -17,6 +17,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "../../include/trhip.h"
 #include "ShaderInterop.h"
 
@@ -58,6 +60,7 @@ struct trhip_device_t
     static constexpr uint32_t kSideRuns = 16;
     hipStream_t sideStream = nullptr;
     hipEvent_t evFork = nullptr;
+    bool forkSignalled = false;                // evFork already carries the completion of the main stream's last kernel (trhip::LaunchTap)
     hipEvent_t runDone[kSideRuns] = {};
     uint64_t sideRunCounter = 0;               // id of the last finished run (ids start at 1)
     uint64_t mainWaitedUpTo = 0;               // the main stream is ordered after all runs <= this id
@@ -291,6 +294,23 @@ struct ShaderRegistrar
 {
     ShaderRegistrar(const char* name, RecordFn fn, int variant = 0) { registerShader(name, fn, variant); }
 };
+
+// FORKS THROUGH THE KERNEL'S COMPLETION SIGNAL.  The side stream continues from a point of the main stream (a fork).
+// hipEventRecord there puts a marker packet into the main queue: 2.9 us of the frame's chain of dependent launches, 5.3 us
+// with the side stream's wait (tools/sync_cost.hip, profiles/r4/sync_cost.txt).  hipExtLaunchKernelGGL hands the event the
+// completion signal of the kernel itself: 1.6 us.  While trhip_queue_execute runs the main-stream command in front of a fork
+// it sets a tap; the command's FIRST launch on that stream (every launch of the back end goes through TRHIP_LAUNCH) carries
+// the fork event.  A command with more than one launch falls back to the marker (the queue loop checks `launches`).
+struct LaunchTap { hipStream_t onStream = nullptr; hipEvent_t stopEvent = nullptr; int launches = 0; };
+extern thread_local LaunchTap* g_launchTap;
+#define TRHIP_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                       \
+    do {                                                                                                            \
+        trhip::LaunchTap* tap_ = trhip::g_launchTap;                                                                \
+        if (tap_ && tap_->onStream == (stream) && tap_->launches++ == 0)                                              \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, nullptr, tap_->stopEvent, 0, __VA_ARGS__);    \
+        else                                                                                                        \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                    \
+    } while (0)
 
 inline int launchStatus(const char* what)
 {
