@@ -1,3 +1,5 @@
+"""Diagnostic (needs a -DTR_COUNT_PATHS build in TRHIP_LIB): how many meshlets of a frame the deferred mode of the cull kernel
+sends to their exact re-evaluation, in how many fix passes."""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,6 +21,8 @@ L.trhip_debug_read_stamps(out, 1)
 r.set_camera(view); r.frame()
 r.wait_idle()
 L.trhip_debug_read_stamps(out, 1)
-print("batches", out[0], "with fixups", out[1], "deferred lookups", out[2], "overflows", out[3])
-print("wave-steps on the fast arithmetic path", out[4], "on the exact path", out[5], "(needs -DTR_COUNT_PATHS)")
+res = r.results()
+tested = sum(bench.gs_num_meshlets(spec, res[s]["records"]) for s in (0, 1) if res[s] is not None)
+print(f"one frame ({tested} meshlets tested): deferred meshlets {out[0]} ({100.0 * out[0] / max(tested, 1):.3f} %) in {out[1]} waves' regions, batches redone exactly in place {out[2]}, meshlets re-evaluated in place (region full) {out[3]}")
+print("wave-steps of the texel-path kernel on the fast arithmetic path", out[4], "on the exact path", out[5], "(needs -DTR_COUNT_PATHS)")
 r.shutdown()

@@ -77,7 +77,9 @@ int main()
                     if (i) CK(hipStreamWaitEvent(A, f[0], 0));
                     hipLaunchKernelGGL(busy, grid, block, 0, A, longK, nullptr, nullptr, 0u);
                     if (i == 0) { hipLaunchKernelGGL(busy, dim3(64), block, 0, B, shortK, nullptr, nullptr, 0u); CK(hipEventRecord(f[0], B)); } break;
-                case 5:   // fork through the kernel's own completion signal (ONE event reused for every fork, as the back end does; B checks the dependency)
+                case 5:   // fork through the kernel's own completion signal (ONE event reused for every fork, and given to TWO launches, as the
+                          // back end does; B checks that it sees the SECOND one's result)
+                    hipExtLaunchKernelGGL(busy, dim3(8), block, 0, A, nullptr, e[0], 0, shortK, nullptr, nullptr, 0u);
                     hipExtLaunchKernelGGL(busy, grid, block, 0, A, nullptr, e[0], 0, longK, ticketA, flagA, epoch);
                     CK(hipStreamWaitEvent(B, e[0], 0)); hipLaunchKernelGGL(checkThenBusy, dim3(64), block, 0, B, shortK, flagA, epoch, violations); break;
                 case 6:   // fork + late join, both through completion signals

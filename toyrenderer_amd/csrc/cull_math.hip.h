@@ -38,6 +38,8 @@ typedef unsigned long long lmask;
 __device__ __forceinline__ lmask mLt(float a, float b) { lmask m; asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }   // a < b (false for NaN)
 __device__ __forceinline__ lmask mGe(float a, float b) { lmask m; asm("v_cmp_ge_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }   // a >= b (false for NaN)
 __device__ __forceinline__ lmask mAbsGt(float a, float b) { lmask m; asm("v_cmp_gt_f32_e64 %0, |%1|, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }   // |a| > b (false for NaN)
+__device__ __forceinline__ lmask mLe(float a, float b) { lmask m; asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }   // a <= b (false for NaN)
+__device__ __forceinline__ lmask mLtU(uint32_t a, uint32_t b) { lmask m; asm("v_cmp_lt_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
 __device__ __forceinline__ lmask mLeU(uint32_t a, uint32_t b) { lmask m; asm("v_cmp_le_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
 __device__ __forceinline__ lmask mGeU(uint32_t a, uint32_t b) { lmask m; asm("v_cmp_ge_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
 __device__ __forceinline__ lmask mAbsLe(float a, float b) { lmask m; asm("v_cmp_le_f32_e64 %0, |%1|, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }   // |a| <= b (false for NaN)
@@ -476,17 +478,18 @@ __device__ __forceinline__ F3 coneAxisCutoff(uint32_t packed, float* cutoff)
     return { a01.x, a01.y, fma_(q23.x, 2.0f, -1.0f) };
 }
 
-// The same through two 256-entry tables in LDS computed with the arithmetic above: tab[x] = fma(x / 255, 2, -1) (axis component),
-// tab[256 + x] = x / 255 (cutoff): four byte-indexed reads instead of 4 conversions + 7 packed operations per meshlet.
-// Two dense float tables, not one of {axis, cutoff} pairs: the byte-indexed ds_read_b32 of 64 lanes then spread over all 32
-// LDS banks instead of the 16 even (axis) or 16 odd (cutoff) ones (round 3: SQ_LDS_BANK_CONFLICT 28.0 M cycles per launch
-// against 18.6 M LDS-active ones; profiles/r4/experiments.md).
-constexpr uint32_t kConeTabEntries = 512;
-__device__ __forceinline__ float coneTableEntry(uint32_t i) { const float q = u8Unorm(i & 0xFFu); return i < 256u ? fma_(q, 2.0f, -1.0f) : q; }
+// The same through a 256-entry table in LDS, tab[x] = x / 255 computed with the arithmetic above; the axis components take their
+// fma(q, 2, -1) from there (three plain fma: the same operation on the same operand as in coneAxisCutoff).  Four byte-indexed
+// reads instead of 4 conversions + 6 packed operations per meshlet.  One dense float table: the byte-indexed ds_read_b32 of
+// 64 lanes spread over all 32 LDS banks (round 3 kept {axis, cutoff} pairs: every read of a half used 16 banks --
+// SQ_LDS_BANK_CONFLICT 28.0 M cycles per launch, 17.9 M with dense tables; profiles/r4/experiments.md), and 1 KB instead of 2
+// (the deferred list needs the LDS: 5 workgroups per CU want <= 32 000 bytes each).
+constexpr uint32_t kConeTabEntries = 256;
+__device__ __forceinline__ float coneTableEntry(uint32_t i) { return u8Unorm(i & 0xFFu); }
 __device__ __forceinline__ F3 coneAxisCutoffLds(uint32_t packed, float* cutoff, const float* tab)
 {
-    *cutoff = tab[256u + (packed >> 24)];
-    return { tab[packed & 0xFFu], tab[(packed >> 8) & 0xFFu], tab[(packed >> 16) & 0xFFu] };
+    *cutoff = tab[packed >> 24];
+    return { fma_(tab[packed & 0xFFu], 2.0f, -1.0f), fma_(tab[(packed >> 8) & 0xFFu], 2.0f, -1.0f), fma_(tab[(packed >> 16) & 0xFFu], 2.0f, -1.0f) };
 }
 
 #ifdef TR_COUNT_PATHS
@@ -644,6 +647,108 @@ __device__ __forceinline__ void stepQuotients(lmask active, F3 c, float r, uint3
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// FILTERED PROJECTION (round 4; the footprint-table kernel of large passes).  culling.hlsli:53-78 turns the view-space sphere
+// into the mip level and the footprint origin of ONE table lookup through two exact square roots, four exact quotients, a
+// floor(log2) and two floors.  Everything the meshlet's visibility takes from that chain are three INTEGERS (level, x0, y0;
+// the zero-weight flags are "fraction == 0").  The fast path below computes the chain approximately -- closed form, one
+// v_rsq_f32 per axis, ONE v_rcp_f32 for both -- together with a proven bound on how far its real-valued intermediates can be
+// from the reference's; a lane is SURE when no integer can differ inside that bound.  A lane that is not sure, and whose
+// lookup still matters, is written to a list and re-evaluated with the exact sequences by a fix-up kernel behind the cull
+// (k_basepass_as.hip: deferred list); the bits the cull stored for it are overwritten.  Nothing is decided approximately.
+//
+// Closed form.  With Z = c.z^2 - r^2, v = sqrt(c.x^2 + Z):   (v c.x -+ c.z r) / (v c.z +- c.x r) = (c.x c.z -+ v r) / Z
+// (multiply numerator and denominator by (v c.z -+ c.x r); v^2 c.z^2 - c.x^2 r^2 = Z (c.x^2 + c.z^2)).  Same for y.
+//
+// Preconditions of a sure lane (projSure): 8 |r| <= c.z, |c.x| <= Bx c.z, |c.y| <= By c.z, c.z <= 2^30 -- and, wave-uniform,
+// nearPlane in [2^-20, 2^20] (a lane that still matters has c.z - r >= nearPlane, so c.z >= 0.88 * 2^-20: no intermediate
+// leaves the normal range).  Bx = 1.125 / P00 + 0.25 holds every sphere with 8 r <= c.z that touches the frustum.
+//
+// Error bound (u = 2^-24; rho = |r| / c.z <= 1/8; beta = |c.x| / c.z <= B; lengths in units of c.z; q = the quotient's real
+// value; v_rsq_f32 / v_rcp_f32 within 1 ulp = 2 u):
+//   Z  = fma(cz, cz, -RN(r r)) = Z* (1 + eZ), |eZ| <= (rho^2 / (1 - rho^2) + 1) u <= 1.016 u; Z* >= 63/64
+//   X  = fma(cx, cx, Z)        = X* (1 + eX), |eX| <= 2.016 u                  (both are the REFERENCE's values: shared)
+//   reference:  v = RN(sqrt X) = sqrt(X) (1 + d),  |d| <= u;     fast:  v' = RN(X rsq(X)) = sqrt(X) (1 + d'), |d'| <= 3 u
+//   the reference's quotient, as a real function of its v, IS (cx cz - v r + t cx cz) / (Z* + t cz^2) with
+//     t = (v^2 - X*) / (cx^2 + cz^2), |t| <= 2 (|eX| / 2 + u) = 4.02 u
+//   so  q_ref - q_fast  =  - v r (d - d') / Z*  +  t cx cz / Z*  -  q t cz^2 / Z*  +  q eZ   (first order), i.e.
+//     <= u (4 sqrt(B^2 + 1) rho + 4.02 B + (4.02 + 1.016) |q|) / (63/64)
+//   rounding of the reference's remaining operations (two products, two fma, one division; d1 >= 0.85 v >= 0.85 beta):
+//     <= u (rho / d1 + |q| beta rho / d1 + 3 |q|) <= u (0.15 + 3.15 |q|)
+//   rounding of the fast path's (product, fma, v_rcp_f32, product):  <= u (beta / Z* + 4 |q|) <= u (1.016 B + 4 |q|)
+//   |q_ref - q_fast| <= Cq u,  Cq = 0.51 sqrt(B^2 + 1) + 5.11 B + 0.15 + 12.3 |q|,  |q| <= 1 / P + (slack) wherever the
+//   clamp to [-1, 1] (:64-67) lets a difference through.  kProjMargin (1.0625) covers the second-order terms (tools/proj_filter_check.c: the largest difference seen is 0.25 of the bound).
+//   Downstream (every operation 1-Lipschitz or a product with an exact constant; RN(a) - RN(b) <= |a - b| + u |a| + u |b|):
+//     clamp(q P): E1 = P Cq u + 2 u;  ClipXYToUV: E1 / 2 + 2 u;  lo + hi: E1 + 8 u;  f = fma(lo + hi, dim / 2, -0.5):
+//     |f - f'| <= (dim / 2) (E1 + 12 u) = (dim / 2) K u,   K = P Cq + 14
+//     width = (hi - lo) dimension:  |w - w'| <= W (E1 + 6 u) + 2 u w
+//   floor(f) and the zero-weight flag (f == floor f) agree if  K u dim / 2 < frac(f') < 1 - K u dim / 2;
+//   floor(log2(max(w, h, 1))) agrees if no power of two >= 2 lies within W (E1 + 6 u) + 2 u m of m' = max(w', h', 1): in
+//   mantissa units of m' in [2^k, 2^(k+1)) that is (mipDelta >> k) + 4 (projMipDelta).
+// tools/proj_filter_check.c replays both chains on the CPU with v_rsq / v_rcp modelled as ANY value within 1 ulp and checks
+// the bounds and the decisions on 10^9 random and adversarial spheres; tests/test_gpu_parity.py puts projections ON texel
+// edges and ON level boundaries +- 0 ... 10^5 ulp (the -DTR_EXP_PROJ_NOBAND build must fail it).
+constexpr float kProjMargin = 1.0625f;
+struct ProjBands               // wave-uniform (scalar registers)
+{
+    v2f invB;                  // (1 / Bx, 1 / By)
+    v2f K;                     // (Kx, Ky) u: |f - f'| <= K u * (dim / 2), margin included
+    uint32_t mipDelta;         // mantissa units (2^-23) a power of two must stay away from m' = max(w', h') in [1, 2); in [2^k, 2^(k+1)): (mipDelta >> k) + 4
+    float mFloor;              // 1 + (mipDelta + 4) 2^-23: the floor of max(w', h', .) -- below 2 everything is level 0
+};
+__host__ __device__ inline ProjBands projBands(float P00, float P11, uint32_t hzbWidth, uint32_t hzbHeight)
+{
+    const float u = 0x1p-24f;
+    ProjBands b;
+    float K[2], invB[2];
+    const float P[2] = { __builtin_fabsf(P00), __builtin_fabsf(P11) }, dim[2] = { (float)hzbWidth, (float)hzbHeight };
+    float wBand = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float B = 1.125f / P[i] + 0.25f;
+        const float qmax = 1.0f / P[i] + 0x1p-10f;
+        const float Cq = kProjMargin * (0.51f * __builtin_sqrtf(B * B + 1.0f) + 5.11f * B + 0.15f + 12.3f * qmax);
+        const float E1 = P[i] * Cq + 2.0f;                           // in units of u
+        K[i] = (E1 + 12.0f) * u;
+        invB[i] = 1.0f / B;
+        wBand = __builtin_fmaxf(wBand, dim[i] * (E1 + 6.0f) * u);
+    }
+    b.invB = v2f{ invB[0], invB[1] };
+    b.K = v2f{ K[0], K[1] };
+#ifdef TR_EXP_PROJ_NOBAND     /* mutation test (results WRONG by design): the boundary test must fail without the bands */
+    b.K = v2f{ 0.f, 0.f };
+    wBand = 0.f;
+#endif
+    // |m - m'| <= wBand + 2 u m;  for m' in [2^k, 2^(k+1)) the distance to either end is (mantissa units) 2^(k-23) >= wBand + 2 u m
+    // <=> mantissa units >= wBand 2^(23-k) + 2: projMipDelta(b, e), e = k + 1 (what v_frexp_exp_i32_f32 returns)
+    const float d = wBand * 0x1p23f;
+    b.mipDelta = d < 0x1p21f ? (uint32_t)d + 1u : 0x200000u;         // (2^21: every lane unsure -- a P or an HZB beyond any use)
+    b.mFloor = 1.0f + (float)(b.mipDelta + 4u) * 0x1p-23f;
+    return b;
+}
+
+__host__ __device__ inline uint32_t projMipDelta(const ProjBands& b, uint32_t e /* >= 1 */) { return (b.mipDelta >> (e - 1u)) + 4u; }
+
+// culling.hlsli:56-62 in closed form, approximately (see above): (minx, miny), (maxx, maxy); `sure` = the preconditions.
+template <bool CZ_BOUNDED /* the caller's own checks already bound c.z (the cone's: c.c <= 2^60) */>
+__device__ __forceinline__ void projectFiltered(F3 c, float r, const ProjBands& b, v2f& mn, v2f& mx, lmask& sure)
+{
+    const v2f cxy = { c.x, c.y };
+    const float Z = fma_(c.z, c.z, -(r * r));                         // :54
+    const v2f X = fma2(cxy, cxy, splat2(Z));                          // :56, :60 radicands
+    const v2f y = { __builtin_amdgcn_rsqf(X.x), __builtin_amdgcn_rsqf(X.y) };
+    const float rD = __builtin_amdgcn_rcpf(Z);
+    const v2f vv = X * y;                                             // vx, vy
+    const v2f a = cxy * splat2(c.z);
+    const v2f mnN = fma2(-vv, splat2(r), a), mxN = fma2(vv, splat2(r), a);
+    mn = mnN * splat2(rD);
+    mx = mxN * splat2(rD);
+    const v2f h = cxy * b.invB;
+    const float m3 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(h.x), __builtin_fabsf(h.y)), __builtin_fabsf(r) * 8.0f);
+    sure = mLe(m3, c.z);                                              // false for NaN
+    if (!CZ_BOUNDED) sure &= mLe(c.z, 0x1p30f);
+}
+
 // culling.hlsli:64-78 from the four quotients on: clamp, ClipXYToUV, mip level, footprint origin.
 struct OccUv { v2f uv; int mip; };
 __device__ __forceinline__ v2f occClampUv(v2f m, v2f P)
@@ -687,6 +792,87 @@ __device__ __forceinline__ OccQuad occTailQuad(const StepQuot& q, F3 c, float r,
         o.slow = __builtin_amdgcn_ballot_w64((bx & (x0 >= 0) & (x0 + 1 < mw)) | (by & (y0 >= 0) & (y0 + 1 < mh)));
     }
     o.depthSphere = q.depthSphere;
+    return o;
+}
+
+// One cull step of the DEFERRED mode (footprint-table kernel): nothing here is exact-or-fallback, every lane gets the fast
+// values and a verdict on whether they decide what the reference decides:
+//   projection  projectFiltered (above), sureOcc = its preconditions (the bands are added by occTailQuadFiltered);
+//   depthSphere nearPlane / (c.z - r), the compiler's Newton iteration without v_div_scale / v_div_fmas / v_div_fixup: exact
+//               under the same preconditions (see stepQuotients: operands >= 2^-30, nearPlane in [2^-20, 2^20]);
+//   cone        t * rsq(t.t), c.c * rsq(c.c) as in stepQuotients' fast path; sureCone = the radicands in [2^-96, 2^60] and
+//               |r| <= 2^30 (coneBack's analysis needs that); its 2^-18 band is checked by coneBackSure.
+template <bool CONE>
+__device__ __forceinline__ void stepDeferred(F3 c, float r, uint32_t packed, const M33P& adj, float nearPlane, const ProjBands& bands, const float* coneTab,
+                                             StepQuot& o, lmask& sureOcc, lmask& sureCone)
+{
+    projectFiltered<CONE>(c, r, bands, o.mn, o.mx, sureOcc);
+    const float dz = c.z - r;
+    const float rc = __builtin_amdgcn_rcpf(dz);
+    const float r3 = fma_(fma_(-dz, rc, 1.0f), rc, rc);
+    o.depthSphere = quotient1(nearPlane, dz, r3);                      // culling.hlsli:79
+    o.coneExact = false;
+    o.cutoff = 0.0f; o.lenC = 0.0f; o.tn = { 0.0f, 0.0f, 0.0f };
+    sureCone = ~0ull;
+    if (CONE) {
+        const F3 a = coneAxisCutoffLds(packed, &o.cutoff, coneTab);
+        const F3 t = mulVecP(a, adj);                                  // basepass.hlsl:103 mul(axis, adjugate)
+        const float st = dot3(t, t), sc = dot3(c, c);
+        const v2f rlen = { __builtin_amdgcn_rsqf(st), __builtin_amdgcn_rsqf(sc) };
+        const v2f txy = v2f{ t.x, t.y } * splat2(rlen.x), tzl = v2f{ t.z, sc } * rlen;
+        o.tn = { txy.x, txy.y, tzl.x };
+        o.lenC = tzl.y;
+        // radicands in [2^-96, 2^60] (negative / NaN read as huge) and |r| <= 2^30 <=> r r <= 2^60: one compare for the three upper bounds
+        const uint32_t uMin = min(__float_as_uint(st), __float_as_uint(sc));
+        const uint32_t uMax = max(max(__float_as_uint(st), __float_as_uint(sc)), __float_as_uint(r * r));
+        sureCone = mGeU(uMin, 0x0F800000u) & mLeU(uMax, 0x5D800000u);
+        sureOcc &= sureCone;                                               // (c.c <= 2^60 is projectFiltered's bound on c.z)
+    }
+}
+
+// coneBack for the deferred mode: the fast decision and whether it is certain (outside the 2^-18 band, see coneBack).
+__device__ __forceinline__ lmask coneBackSure(const StepQuot& q, F3 cv, float r, const M33P& viewRot, float kV, lmask& sure)
+{
+    F3 axis = mulVecP(q.tn, viewRot);
+    axis.z = -axis.z;
+    const float D = dot3(cv, axis), R = fma_(q.cutoff, q.lenC, r);
+#ifndef TR_EXP_CONE_NOBAND
+    const float E = fma_(q.lenC, kV, __builtin_fabsf(r)) * 0x1p-18f;
+    sure &= mAbsGt(D - R, E);                                          // false for NaN
+#endif
+    return mGe(D, R);
+}
+
+// The same from the FILTERED quotients (projectFiltered): the table index of the lookup and, per lane, whether level, footprint
+// origin and zero-weight flags are certain to be the reference's (`sure`, ANDed into the caller's).  A sure lane's lookup is
+// never one the table cannot serve (its fractions are > 0), so there is no `slow` here.
+__device__ __forceinline__ OccQuad occTailQuadFiltered(v2f mn, v2f mx, float depthSphere, F3 c, float r, float nearPlane, float P00, float P11, const Hzb& h,
+                                                       const uint4* mipTab, const uint2* mipBand /* [e] = { projMipDelta(e), twice that } */, uint32_t quadTotal,
+                                                       const ProjBands& b, lmask& sure)
+{
+    OccQuad o;
+    o.accept = mLt(c.z - nearPlane, r);                                // :48-49 (exact)
+    const v2f P = { P00, P11 };
+    const v2f lo = occClampUv(mn, P), hi = occClampUv(mx, P);
+    const v2f wh = (hi - lo) * v2f{ (float)h.width, (float)h.height }; // :73-74
+    const float m = max_(max_(wh.x, wh.y), b.mFloor);                  // :75; NaN -> mFloor
+    int e = __builtin_amdgcn_frexp_expf(m);
+    e = e < (int)h.mips ? e : (int)h.mips;
+    e = e > 1 ? e : 1;
+    const uint4 tab = mipTab[e];
+    const v2f half = { __uint_as_float(tab.z), __uint_as_float(tab.w) };
+    const v2f f = fma2(lo + hi, half, splat2(-0.5f));                  // :78 + the sampler's uv * dim - 0.5 (see occTailQuad)
+    const v2f fl = { __builtin_floorf(f.x), __builtin_floorf(f.y) };
+    const int x0 = (int)fl.x, y0 = (int)fl.y;
+    o.iq = min(quadIndex(tab.x, tab.y, (uint32_t)(x0 + 1), (uint32_t)(y0 + 1)), quadTotal - 1u);
+    // bands: |frac - 1/2| <= 1/2 - K u dim / 2 on both axes (false for NaN); no power of two within mipDelta mantissa units
+    const v2f t = f - (fl + splat2(0.5f));
+    const v2f cap = fma2(half, -b.K, splat2(0.5f));
+    const uint2 band = mipBand[e];
+    const uint32_t mb = __float_as_uint(m) + band.x;
+    sure &= mAbsLe(t.x, cap.x) & mAbsLe(t.y, cap.y) & mGeU(mb & 0x7FFFFFu, band.y);
+    o.slow = 0ull;
+    o.depthSphere = depthSphere;
     return o;
 }
 

@@ -90,7 +90,19 @@ static_assert(kCullSteps % kRingSlots == 0 && kCullBatch <= 64, "a batch is a wh
 constexpr uint32_t kCullWaves = TR_CULL_WAVES;   // meshlet cull: waves per workgroup (= per window of 64 * kCullWaves... records)
 constexpr uint32_t kCullBlock = 64 * kCullWaves;
 constexpr uint32_t kSlotBytes = 1280;            // a ring slot: 64 spheres + 64 cone words (issueMeshletLoads)
-constexpr uint32_t kSlowCap = 32;                // per wave and batch: lookups deferred to the texel path (see OccQuad::slow)
+// Deferred mode (meshletCullKernel): the meshlets whose fast evaluation is not certain wait in the wave's list in LDS (kDefStage
+// entries) for their exact re-evaluation: a pass over the whole list at the first batch boundary that finds kDefPassAt entries
+// or more, and when the wave ends.  An entry: { record index << 5 | lane, view-space centre x, y, z, radius } -- everything the
+// exact OCCLUSION test needs (the frustum test was exact, the cone test certain); centre x = 0xFFFFFFFF marks a meshlet whose
+// CONE test was not certain: that one is re-evaluated from its record (exactMeshletVisible).
+constexpr uint32_t kDefWords = 5;
+constexpr uint32_t kDefStage = 64;
+#ifndef TR_DEF_PASS_AT
+#define TR_DEF_PASS_AT 32
+#endif
+constexpr uint32_t kDefPassAt = TR_DEF_PASS_AT;  // ... of EARLIER batches (C3: ~10 entries per batch of 32 records -> a pass of ~30 entries every third batch)
+constexpr uint32_t kDefFromRecord = 0xFFFFFFFFu;
+static_assert(kDefPassAt <= kDefStage, "deferred list sizes");
 
 struct RecordInfo                                 // per-record invariants parked in LDS (96 B, read as 128-bit words)
 {
@@ -162,6 +174,7 @@ struct MeshletCullArgs
     // the arguments as the list build's input that clear -- the head of the next frame's chain -- had to wait for it (a
     // cross-stream join, exposed: ~20 us per frame on C3, profiles/r4/experiments.md section 2).
     uint32_t* listGroups;
+    cm::ProjBands bands;                          // filtered projection: preconditions and bands (cm::projBands, computed on the host)
 };
 
 __device__ __forceinline__ uint32_t groupCount(const MeshletCullArgs& a)
@@ -248,6 +261,45 @@ __device__ __forceinline__ void issueMeshletLoads(char* slotLds /* wave-uniform 
 #define TR_STAMP(i) do {} while (0)
 #endif
 
+// Exact visibility of meshlet `mi` of instance `cid`, from global memory alone (the path of the texel kernel: every test with the
+// compiler's correctly rounded sequences, basepass.hlsl:65-108).  What the deferred mode's re-evaluations run.
+template <bool FRUSTUM, bool OCCLUSION, bool CONE>
+__device__ __forceinline__ bool exactMeshletAt(const MeshletCullArgs& a, const cm::M43P& VP, const cm::M33P& VR, uint32_t cid, uint64_t mi)
+{
+    const float4* wr = a.cache.world + 4ull * cid;
+    const float4* p = reinterpret_cast<const float4*>(a.meshlets + mi);
+    const float4 q0 = wr[0], q1 = wr[1], q2 = wr[2], q3 = wr[3];
+    const float4 sphere = p[0];
+    const uint32_t cone = __float_as_uint(p[1].x);
+    const cm::F3 r0 = { q0.x, q0.y, q0.z }, r1 = { q0.w, q1.x, q1.y }, r2 = { q1.z, q1.w, q2.x };
+    const cm::M43P W = cm::packM43(cm::M43{ r0, r1, r2, { q2.y, q2.z, q2.w } });
+    const cm::M33P adj = cm::rot(cm::packM43(cm::M43{ cm::cross3(r1, r2), cm::cross3(r2, r0), cm::cross3(r0, r1), { 0.f, 0.f, 0.f } }));
+    const cm::F3 cv = cm::toViewP(cm::mulPointP({ sphere.x, sphere.y, sphere.z }, W), VP);
+    const float rad = sphere.w * q3.x;
+    bool vis = true;
+    if (FRUSTUM) vis &= cm::frustumVisible(cv, rad, a.k.m_Frustum.x, a.k.m_Frustum.y, a.k.m_Frustum.z, a.k.m_Frustum.w);
+    if (OCCLUSION) vis &= cm::occlusionVisible(cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb);
+    float unused;
+    if (CONE) vis &= !cm::coneBackfacingP(cone, cv, rad, adj, VR, 1.0f, 1.0f, &unused);
+    return vis;
+}
+// ... of lane m of record g (basepass.hlsl:52-63 first)
+template <bool FRUSTUM, bool OCCLUSION, bool CONE>
+__device__ __forceinline__ bool exactMeshletVisible(const MeshletCullArgs& a, const cm::M43P& VP, const cm::M33P& VR, uint32_t g, uint32_t m)
+{
+    const MeshletAmplificationData rec = a.records[g];
+    const uint32_t cid = rec.m_InstanceConstIdx < a.numInstances ? rec.m_InstanceConstIdx : 0u;
+    const uint32_t lodIdx = rec.m_MeshLOD < kMaxNumMeshLODs ? rec.m_MeshLOD : kMaxNumMeshLODs - 1u;
+    const uint2 li = a.cache.lod(cid, lodIdx);
+    const uint32_t off = rec.m_MeshletGroupOffset;
+    uint32_t cnt = li.x > off ? li.x - off : 0u;
+    const uint64_t base = (uint64_t)li.y + off;
+    cnt = cnt < 32u ? cnt : 32u;
+    if (base + cnt > a.numMeshlets) cnt = 0;
+    if (m >= cnt) return false;
+    return exactMeshletAt<FRUSTUM, OCCLUSION, CONE>(a, VP, VR, cid, base + m);
+}
+
 // TABLE: resolve the HZB lookup through the footprint-min table (one 2-byte load; the early pass, where the
 // table is rebuilt once per frame behind the instance pass) or through the texels themselves (two texel-pair
 // loads; the late pass, which is small and follows an HZB rebuild).  Same results either way.
@@ -282,9 +334,10 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
     __shared__ uint32_t s_gIdxAll[kCullWaves][kCullBatch];
     __shared__ uint32_t s_quadOff[16];                 // texel path: mip offsets
     __shared__ uint4 s_mipTab[17];                     // table path: per-mip constants indexed by exponent + 1 (cm::occTailQuad)
-    __shared__ float s_coneTab[cm::kConeTabEntries];   // cone byte -> axis component [0, 256), cutoff [256, 512) (cm::coneTableEntry)
-    __shared__ uint32_t s_slowAll[kCullWaves][kSlowCap];
-    __shared__ uint32_t s_slowCount[kCullWaves];
+    __shared__ float s_coneTab[cm::kConeTabEntries];   // cone byte -> byte / 255 (cm::coneTableEntry)
+    constexpr bool kDeferred = OCCLUSION && TABLE;     // the deferred mode (below); the other instantiations decide every lane exactly in place
+    __shared__ uint2 s_mipBand[kDeferred ? 17 : 1];    // deferred mode: per level, the band of the level decision (cm::projMipDelta)
+    __shared__ uint32_t s_defAll[kCullWaves][kDeferred ? kDefStage * kDefWords : 1u];   // per wave: the deferred list (kDefWords words per entry)
     __shared__ __attribute__((aligned(8))) uint32_t s_maskAll[kCullWaves][kCullBatch + 2];   // [0], [1]: where the deferred resolve of "the step before the first" lands
     __shared__ __attribute__((aligned(16))) char s_ring[kCullWaves][kRingSlots][kSlotBytes];   // per wave: the ring slots of the staged meshlet cull stream
 
@@ -305,12 +358,12 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
         const uint32_t mw = (a.hzb.width >> mip) ? (a.hzb.width >> mip) : 1u, mh = (a.hzb.height >> mip) ? (a.hzb.height >> mip) : 1u;
         s_mipTab[tid] = make_uint4(a.quad.offset[mip], ((mw >> 3) + 1u) * 64u, __float_as_uint(0.5f * (float)mw), __float_as_uint(0.5f * (float)mh));
     }
+    if (kDeferred && tid >= 1 && tid <= 16) { const uint32_t d = cm::projMipDelta(a.bands, tid); s_mipBand[tid] = make_uint2(d, 2u * d); }
     // the fast arithmetic path wants nearPlane in [2^-20, 2^20] (cm::stepQuotients)
     const bool nearInRange = a.k.m_NearPlane >= 0x1p-20f && a.k.m_NearPlane <= 0x1p20f;
     if (CONE) for (uint32_t i = tid; i < cm::kConeTabEntries; i += kCullBlock) s_coneTab[i] = cm::coneTableEntry(i);   // (any workgroup size: TR_CULL_WAVES)
-    if (tid < kCullWaves) s_slowCount[tid] = 0;
     if (lane < 2 * kRingSlots) { s_recAll[wave][kCullBatch + lane].first = 0; s_recAll[wave][kCullBatch + lane].lastOff = 0; }
-    uint32_t* s_slow = s_slowAll[wave];
+    uint32_t* s_def = s_defAll[wave];
     uint32_t* s_mask = s_maskAll[wave];
     __syncthreads();                                                                 // the only workgroup barrier
 
@@ -376,6 +429,76 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
     uint32_t s0 = 0, s1 = kCullSteps, sbNext, s0n, s1n;
     uint32_t sb = windowOf(0u, s0, s1);
     uint4 entry = loadEntry(sb);
+    // ---- DEFERRED MODE (kDeferred: the footprint-table kernel of large passes) ---------------------------------------------
+    // The step loop evaluates every meshlet with FAST arithmetic only (cm::stepDeferred: closed-form projection from one
+    // v_rsq_f32 per axis and one v_rcp_f32, cone from v_rsq_f32) and, with it, whether the fast values are certain to decide
+    // what the reference's exact square roots and divisions decide (cm::projectFiltered has the proof).  A meshlet that is
+    // not certain and still matters goes on the wave's deferred list (kDefWords above) and the bit the loop stored for it is
+    // OVERWRITTEN later by the exact evaluation: 64 listed meshlets at a time, at batch boundaries, behind the batch's mask
+    // store (a wave owns its records: only it touches their mask words), the rest when the wave ends.  On C3 about 0.9 % of the
+    // tested meshlets take that way: 1.6 passes of ~200 instructions per wave and launch instead of the exact sequences in every
+    // one of the wave's 170 steps (rounds 2-3).  The exact pass resolves its lookups through the table, like the loop.
+    uint32_t stCount = 0u;                             // wave-uniform: entries in the list (s_def)
+    uint32_t stAtBatch = 0u;                           // ... when the current batch began
+    bool batchExact = false;                           // wave-uniform: the list overflowed inside this batch -> the batch is redone exactly, in place, and its entries dropped
+    auto exactMeshlet = [&](uint32_t g, uint32_t m) -> bool { return exactMeshletVisible<FRUSTUM, OCCLUSION, CONE>(a, VP, VR, g, m); };
+    // the exact occlusion test of a listed meshlet from its view-space sphere (culling.hlsli:36-82 with the compiler's correctly
+    // rounded sequences), the lookup through the table like the loop's (cm::occTailQuad), through the texels where the table
+    // cannot serve it (a zero bilinear weight)
+    auto exactOcclusion = [&](cm::F3 c, float r) -> bool {
+        cm::StepQuot q;
+        const float crx = c.x * r, cry = c.y * r, crz = c.z * r;                          // :53
+        const float czr2 = cm::fma_(c.z, c.z, -(r * r));                                  // :54
+        const float vx = cm::sqrt_(cm::fma_(c.x, c.x, czr2)), vy = cm::sqrt_(cm::fma_(c.y, c.y, czr2));   // :56, :60
+        q.mn = cm::v2f{ cm::div_(cm::fma_(vx, c.x, -crz), cm::fma_(vx, c.z, crx)), cm::div_(cm::fma_(vy, c.y, -crz), cm::fma_(vy, c.z, cry)) };   // :57, :61
+        q.mx = cm::v2f{ cm::div_(cm::fma_(vx, c.x, crz), cm::fma_(vx, c.z, -crx)), cm::div_(cm::fma_(vy, c.y, crz), cm::fma_(vy, c.z, -cry)) };   // :58, :62
+        q.depthSphere = cm::div_(a.k.m_NearPlane, c.z - r);                               // :79
+        const cm::OccQuad oq = cm::occTailQuad(q, c, r, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_mipTab, a.quad.total);
+        const float footprintMin = (float)a.quad.base[oq.iq];
+        bool vis = (((oq.accept >> lane) & 1ull) != 0ull) | (oq.depthSphere >= footprintMin);                                 // :48-49, :81
+        if ((oq.slow >> lane) & 1ull) vis = cm::occlusionVisible(c, r, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb);
+        return vis;
+    };
+    // re-evaluate the first `n` listed meshlets (n <= 64) and overwrite their bits in the mask array, then close the gap in the
+    // list.  The caller guarantees that the masks of those meshlets' batches are in memory (a wave owns its records: only it
+    // touches their mask words): inside the kernel a pass runs at the end of a batch, IN FRONT of its mask store, over the
+    // entries of EARLIER batches -- their stores were issued a batch ago and the batch's final s_waitcnt vmcnt(0) has covered
+    // them -- so a pass waits for nothing but its own table lookups.
+    auto runPass = [&](uint32_t n) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef TR_COUNT_PATHS
+        if (lane == 0) { atomicAdd(&g_stampSums[0], (unsigned long long)n); atomicAdd(&g_stampSums[1], 1ull); }   // deferred meshlets, passes
+#endif
+#ifndef TR_EXP_NOFIX      /* experiment, results WRONG: the listed meshlets are dropped -- what their exact re-evaluation costs */
+        {
+            // every lane runs along (cm::occTailQuad works on wave-wide lane masks): the lanes past n re-read entry 0
+            const uint32_t* src = s_def + (lane < n ? lane : 0u) * kDefWords;
+            const uint32_t e = src[0], w1 = src[1], g = e >> 5, m = e & 31u;
+            const cm::F3 c = { __uint_as_float(w1), __uint_as_float(src[2]), __uint_as_float(src[3]) };
+            const float r = __uint_as_float(src[4]);
+            bool vis = exactOcclusion(c, r);
+            if (w1 == kDefFromRecord) vis = exactMeshlet(g, m);                          // (cone not certain; or, harmlessly, a centre whose x has this bit pattern)
+            if (lane < n) {
+                if (vis) atomicOr(&a.visMask[g], 1u << m);
+                else atomicAnd(&a.visMask[g], ~(1u << m));
+            }
+        }
+#endif
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // close the gap: entries [n, stCount) move to the front (the list holds at most 64 * 5 words: five words per lane)
+        const uint32_t left = (stCount - n) * kDefWords;
+        uint32_t v[kDefWords];
+#pragma unroll
+        for (uint32_t k = 0; k < kDefWords; ++k) v[k] = lane + 64u * k < left ? s_def[n * kDefWords + lane + 64u * k] : 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (uint32_t k = 0; k < kDefWords; ++k) if (lane + 64u * k < left) s_def[lane + 64u * k] = v[k];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        stCount -= n;
+    };
     for (uint32_t it = 0; sb != 0xFFFFFFFFu; ++it, sb = sbNext, s0 = s0n, s1 = s1n) {
         sbNext = windowOf(it + 1u, s0n, s1n);
         const uint32_t sbBase = sb * superSize;
@@ -393,6 +516,7 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
         nSteps = nSteps < s1 ? nSteps : s1;                                          // this team's piece of the window: steps [s0, nSteps)
         if (s0 >= nSteps) break;                                                     // (only a piece of the partial last window can be empty: the last iteration)
         TR_STAMP(0);   // between batches
+        stAtBatch = stCount;
         // ---- prologue: lane l resolves its record (basepass.hlsl:52-58) through the instance cull cache: ONE
         //      level of dependent loads here -- the entry itself was fetched while the previous batch ran ------
         {
@@ -527,19 +651,27 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
             if (FRUSTUM)
                 vis &= cm::frustumVisibleM(cv, rad, a.k.m_Frustum.x, a.k.m_Frustum.y, a.k.m_Frustum.z, a.k.m_Frustum.w); // :73
             TR_STAMP(2);   // wait for data + transform + frustum
-            // every square root and division of the step (:56-62, :79, normalize :103): fast when the whole wave can
-            cm::StepQuot q;
-            if (OCCLUSION || CONE)
-                cm::stepQuotients<OCCLUSION, CONE, true>(active, cv, rad, cone, adjugateOf(ri), a.k.m_NearPlane, nearInRange, q, s_coneTab);
-            if (CONE)                                                                              // :104-108
-                vis &= ~cm::coneBack(q, cv, rad, VR, coneSlack, vis, cone, adjugateOf(ri));
-            TR_STAMP(3);   // quotients + cone
             cm::lmask accept = 0ull;
             bool pair = false;
             float depthSphere = 0.f;
-            if (OCCLUSION && TABLE) {                                                              // :75-88 (Q4)
-                const cm::OccQuad oq = cm::occTailQuad(q, cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_mipTab, a.quad.total);
+            cm::StepQuot q;
+            if (kDeferred) {
+                // ---- deferred mode: fast values + certainty; the uncertain lanes that still matter go on the list ------------
+                cm::lmask sureOcc, sureCone;
+                cm::stepDeferred<CONE>(cv, rad, cone, adjugateOf(ri), a.k.m_NearPlane, a.bands, s_coneTab, q, sureOcc, sureCone);
+                cm::lmask coneUnsure = 0ull;
+                if (CONE) {                                                                        // :104-108
+                    const cm::lmask back = cm::coneBackSure(q, cv, rad, VR, coneSlack, sureCone);
+                    coneUnsure = vis & ~sureCone;                                                  // passed the frustum; the cone test is within its band
+                    vis &= ~back;
+                }
+                cm::lmask unsure = coneUnsure;
+                TR_STAMP(3);   // quotients + cone
+                const cm::OccQuad oq = cm::occTailQuadFiltered(q.mn, q.mx, q.depthSphere, cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb,
+                                                                s_mipTab, s_mipBand, a.quad.total, a.bands, sureOcc);   // :75-88 (Q4)
+                if (!nearInRange) sureOcc = 0ull;
                 accept = oq.accept; depthSphere = oq.depthSphere;
+                unsure |= vis & ~oq.accept & ~sureOcc;                                             // its lookup matters and level / footprint are within their bands
                 // The one 2-byte load of the lookup -- only for the lanes whose meshlet is still in the race and not
                 // accepted at the near plane (:48-49): the tests are pure, so skipping a lookup whose result cannot
                 // matter changes nothing, and a third fewer scattered requests reach the L1.
@@ -547,20 +679,31 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
 #ifdef TR_NO_LOOKUP      /* experiment, results WRONG: what the kernel would cost if the lookups were free */
                 issueLookup(lk0[kSlot], lk1[kSlot], a.quad.base, a.quad.base, 0ull);
                 asm volatile("" :: "v"(entry));
-#elif defined(TR_EXP_LK_MODE)   /* experiment, results WRONG: 1 = every lane of a lookup reads the same line, 2 = the lanes' own entries folded into 4 KB (L1 hits) */
-                const uint16_t* e2 = reinterpret_cast<const uint16_t*>(a.quad.base) + (TR_EXP_LK_MODE == 1 ? (lane & 31u) : (oq.iq & 2047u));
-                issueLookup(lk0[kSlot], lk1[kSlot], e2, e2, vis & ~oq.accept);
 #else
                 issueLookup(lk0[kSlot], lk1[kSlot], entry, entry, vis & ~oq.accept);
 #endif
-                // A lookup whose footprint is NOT the table's (a zero bilinear weight) is only noted here and the
-                // meshlet is re-evaluated with the texel path after the batch (fixups below).  Rare.
-                if (__builtin_expect(oq.slow != 0ull, 0)) {
-                    if ((oq.slow >> lane) & 1ull) {
-                        const uint32_t idx = atomicAdd(&s_slowCount[wave], 1u);
-                        if (idx < kSlowCap) s_slow[idx] = (r << 5) | sub;
+                if (__builtin_expect(unsure != 0ull, 0)) {
+                    const uint32_t n = (uint32_t)__builtin_popcountll(unsure);
+                    if (stCount + n > kDefStage) {
+                        batchExact = true;                                                         // (dozens of uncertain lanes in one batch: hostile data, or meshlets at the camera)
+                    } else {
+                        const uint32_t at = stCount + __builtin_amdgcn_mbcnt_hi((uint32_t)(unsure >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)unsure, 0u));
+                        if ((unsure >> lane) & 1ull) {
+                            uint32_t* d = s_def + at * kDefWords;
+                            d[0] = (s_gIdx[r] << 5) | sub;
+                            d[1] = CONE && ((coneUnsure >> lane) & 1ull) ? kDefFromRecord : __float_as_uint(cv.x);
+                            d[2] = __float_as_uint(cv.y); d[3] = __float_as_uint(cv.z); d[4] = __float_as_uint(rad);
+                        }
+                        stCount += n;
                     }
                 }
+            } else {
+            // every square root and division of the step (:56-62, :79, normalize :103): fast when the whole wave can
+            if (OCCLUSION || CONE)
+                cm::stepQuotients<OCCLUSION, CONE, true>(active, cv, rad, cone, adjugateOf(ri), a.k.m_NearPlane, nearInRange, q, s_coneTab);
+            if (CONE)                                                                              // :104-108
+                vis &= ~cm::coneBack(q, cv, rad, VR, coneSlack, vis, cone, adjugateOf(ri));
+            TR_STAMP(3);   // quotients + cone
             }
             if (OCCLUSION && !TABLE) {
                 const cm::OccSample os = cm::occTailTexel(q, cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb, s_quadOff);
@@ -618,58 +761,38 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
         TR_WAIT_VMCNT(0);                               // the last (padding) prefetches: nothing may land in the ring later
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (OCCLUSION && TABLE) {
-            // ---- fixups: meshlets whose occlusion lookup needs the texel path (OccQuad::slow); they patch the
-            //      batch's masks while those are still in LDS ---------------------------------------------------
-            const uint32_t nSlow = s_slowCount[wave];
-#ifdef TR_COUNT_SLOW
-            if (lane == 0) {
-                atomicAdd(&g_stampSums[0], 1ull);                         // batches
-                if (nSlow) atomicAdd(&g_stampSums[1], 1ull);             // batches with fixups
-                atomicAdd(&g_stampSums[2], (unsigned long long)nSlow);   // deferred lookups
-                if (nSlow > kSlowCap) atomicAdd(&g_stampSums[3], 1ull);  // list overflows
+        if (kDeferred && __builtin_expect(batchExact, 0)) {
+            // ---- the list overflowed inside this batch (dozens of uncertain lanes in 32 records: hostile data): the whole
+            //      batch is redone exactly while its masks are still in LDS, and its list entries are dropped ---------------
+            for (uint32_t s = s0; s < nSteps; ++s) {
+                const uint32_t r = 2 * s + half;
+                const uint32_t g = s_gIdx[r];
+                const unsigned long long ballot = __ballot(g < G && exactMeshlet(g, sub));
+                if (sub == 0) s_mask[r + 2u] = half ? (uint32_t)(ballot >> 32) : (uint32_t)ballot;
             }
+            stCount = stAtBatch;
+            batchExact = false;
+#ifdef TR_COUNT_PATHS
+            if (lane == 0) atomicAdd(&g_stampSums[2], 1ull);                            // batches redone exactly
 #endif
-            if (__builtin_expect(nSlow != 0u, 0)) {
-                // exact visibility of meshlet m of batch record r (all tests, texel path for the HZB lookup)
-                auto exactVisible = [&](uint32_t r, uint32_t m) -> bool {
-                    const RecordInfo& ri = s_rec[r];
-                    if (m >= countOf(ri.lastOff)) return false;
-                    const float4* p = reinterpret_cast<const float4*>(a.meshlets + ri.first);
-                    const float4 sphere = p[2u * m];
-                    const uint32_t cone = __float_as_uint(p[2u * m + 1u].x);
-                    const cm::F3 cv = cm::toViewP(cm::mulPointP({ sphere.x, sphere.y, sphere.z }, worldOf(ri)), VP);
-                    const float rad = sphere.w * ri.maxScale;
-                    bool vis = true;
-                    if (FRUSTUM) vis &= cm::frustumVisible(cv, rad, a.k.m_Frustum.x, a.k.m_Frustum.y, a.k.m_Frustum.z, a.k.m_Frustum.w);
-                    vis &= cm::occlusionVisible(cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb);
-                    float unused;
-                    if (CONE) vis &= !cm::coneBackfacingP(cone, cv, rad, adjugateOf(ri), VR, 1.0f, 1.0f, &unused);   // the exact sequences
-                    return vis;
-                };
-                if (nSlow <= kSlowCap) {                                             // patch single bits
-                    if (lane < nSlow) {
-                        const uint32_t e = s_slow[lane], r = e >> 5, m = e & 31u;
-                        if (exactVisible(r, m)) atomicOr(&s_mask[r + 2u], 1u << m);
-                        else atomicAnd(&s_mask[r + 2u], ~(1u << m));
-                    }
-                } else {                                                             // list overflow: redo the whole batch exactly
-                    for (uint32_t s = s0; s < nSteps; ++s) {
-                        const uint32_t r = 2 * s + half;
-                        const unsigned long long ballot = __ballot(exactVisible(r, sub));
-                        if (sub == 0) s_mask[r + 2u] = half ? (uint32_t)(ballot >> 32) : (uint32_t)ballot;
-                    }
-                }
-                if (lane == 0) s_slowCount[wave] = 0;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (kDeferred && __builtin_expect(stAtBatch >= kDefPassAt, 0)) {                 // a pass over the entries of earlier batches
+            const uint32_t n = stAtBatch < 64u ? stAtBatch : 64u;
+            runPass(n);
+            stAtBatch -= n;
         }
         // ---- the batch's 64 masks leave in one store (lane l: record l of the batch) ----------------------------
         {
             const uint32_t g = lane < kCullBatch ? s_gIdx[lane] : 0xFFFFFFFFu;
             if (g < G) a.visMask[g] = s_mask[(lane < kCullBatch ? lane : 0u) + 2u];     // (g is none outside this team's piece of the window)
         }
+    }
+    if (kDeferred && stCount) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // the last batches' mask stores have completed
+        while (stCount) runPass(stCount < 64u ? stCount : 64u);
     }
 #ifdef TR_STAMPS
     if (lane == 0)
@@ -1305,7 +1428,7 @@ void emitListBuild(const trhip::DispatchCtx& ctx, const MeshletCullArgs& a, cons
 template <bool F, bool O, bool C>
 void launchCull(const MeshletCullArgs& a, uint32_t grid, bool table, hipStream_t s)
 {
-    if (O && table) TRHIP_LAUNCH((meshletCullKernel<F, O, C, true>), dim3(grid), dim3(kCullBlock), 0, s, a);
+    if (O && table) TRHIP_LAUNCH((meshletCullKernel<F, O, C, true>), dim3(grid), dim3(kCullBlock), 0, s, a);      // the deferred mode
     else TRHIP_LAUNCH((meshletCullKernel<F, O, C, false>), dim3(grid), dim3(kCullBlock), 0, s, a);
 }
 
@@ -1472,6 +1595,7 @@ int recordASMain(trhip::DispatchCtx& ctx)
     }
     a.listGroups = (uint32_t*)visMask->sidecar;
     ctx.cl->use(a.listGroups, ctx.cl->ops.size(), true);
+    if (useTable) a.bands = cm::projBands(k->m_P00, k->m_P11, hzb->width, hzb->height);
     const uint32_t flags = k->m_CullingFlags & 7u;
     trhip_texture_t* quadOwner = useTable ? hzb : nullptr;
     const bool table = useTable;

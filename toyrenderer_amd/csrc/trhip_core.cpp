@@ -907,7 +907,7 @@ int trhip_queue_execute(trhip_device dev, const trhip_cmdlist* lists, uint32_t n
             if (tapped) { tap.onStream = stream; tap.stopEvent = dev->evFork; trhip::g_launchTap = &tap; }
             int rc = op.fn(stream);
             trhip::g_launchTap = nullptr;
-            if (tapped && tap.launches == 1 && rc == TRHIP_OK) dev->forkSignalled = true;
+            if (tapped && tap.launches >= 1 && rc == TRHIP_OK) dev->forkSignalled = true;
             if (g_hostProfile.on) g_hostProfile.add(op.kind, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count());
             if (rc != TRHIP_OK) return rc;
             if (prof) { TRHIP_HIP(hipEventRecord(e1, stream)); dev->pending.push_back({ op.name, e0, e1 }); }

@@ -299,14 +299,15 @@ struct ShaderRegistrar
 // hipEventRecord there puts a marker packet into the main queue: 2.9 us of the frame's chain of dependent launches, 5.3 us
 // with the side stream's wait (tools/sync_cost.hip, profiles/r4/sync_cost.txt).  hipExtLaunchKernelGGL hands the event the
 // completion signal of the kernel itself: 1.6 us.  While trhip_queue_execute runs the main-stream command in front of a fork
-// it sets a tap; the command's FIRST launch on that stream (every launch of the back end goes through TRHIP_LAUNCH) carries
-// the fork event.  A command with more than one launch falls back to the marker (the queue loop checks `launches`).
+// it sets a tap; EVERY launch of that command on that stream (every launch of the back end goes through TRHIP_LAUNCH) is
+// given the fork event as its stop event -- like a re-recorded event it ends up standing for the last of them (checked by
+// tools/sync_cost.hip: two launches, one event, the waiter sees the second one's result).
 struct LaunchTap { hipStream_t onStream = nullptr; hipEvent_t stopEvent = nullptr; int launches = 0; };
 extern thread_local LaunchTap* g_launchTap;
 #define TRHIP_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                       \
     do {                                                                                                            \
         trhip::LaunchTap* tap_ = trhip::g_launchTap;                                                                \
-        if (tap_ && tap_->onStream == (stream) && tap_->launches++ == 0)                                              \
+        if (tap_ && tap_->onStream == (stream) && ++tap_->launches)                                              \
             hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, nullptr, tap_->stopEvent, 0, __VA_ARGS__);    \
         else                                                                                                        \
             hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                    \
