@@ -736,3 +736,125 @@ def test_cone_test_at_its_decision_boundary(dev, oracle, flags, table):
     finally:
         drv.release()
         gs.release()
+
+
+@pytest.mark.parametrize("kind,flags", [("texel_x", 3), ("texel_y", 7), ("level", 3), ("level", 7), ("depth", 3)])
+def test_projection_filter_at_its_decision_boundaries(dev, oracle, kind, flags):
+    """The footprint-table kernel (deferred mode, k_basepass_as.hip) takes level and footprint origin of a meshlet's HZB lookup
+    from a closed-form projection evaluated with v_rsq_f32 / v_rcp_f32 and decides on them only outside proven bands
+    (cm::projectFiltered); anything inside a band is re-evaluated with the reference's exact square roots and divisions.  Here
+    most meshlets are PUT on the boundaries those bands guard, in float64 from the float32 inputs, and then moved by 0, +-1,
+    +-2 ... +-10^5 ulp of the moved parameter:
+      texel_x / texel_y   the sphere centre is shifted along view-space x / y until uv * dim - 0.5 is an integer: the footprint
+                          origin floor(...) flips there, and the bilinear weight of the second column / row is zero ON it;
+      level               the radius is scaled until max(width, height) of the projected bounds is a power of two >= 2:
+                          floor(log2(...)) flips there;
+      depth               the radius is set so that nearPlane / (c.z - r) EQUALS the (constant) HZB depth.
+    The HZB holds independent random depths in every texel of every level (except `depth`), so a lookup one texel or one level
+    off decides differently about every second time.  Bit-exact against the oracle, like every other case; a build without the
+    bands (-DTR_EXP_PROJ_NOBAND) fails the first four (profiles/r4/experiments.md)."""
+    from toyrenderer_amd.frame import FrameDriver, GpuScene
+    rng = np.random.default_rng(4200 + flags + len(kind))
+    spec = synth.SceneSpec(num_meshes=700, num_instances=700, meshlets_lod0=64, max_lods=1, seed=4242, nonuniform_scale_fraction=0.3,
+                           unique=True, z_near=6.0, z_far=120.0)
+    scene = synth.make_scene(spec)
+    inst, ml, md = scene.instances, scene.meshlets, scene.meshData
+    view = synth.make_view(eye=(0.1, -0.1, 0.3), yaw=0.02, render=(1920, 1080))
+    V = view.worldToView.astype(np.float64)
+    P00, P11 = float(view.viewToClip[0, 0]), float(view.viewToClip[1, 1])
+    near = float(view.nearPlane)
+    hw, hh = view.hzb_dims
+    hzb = oracle.HzbTexture(hw, hh)
+    d0 = np.float16(near / 60.0)                                                                  # `depth`: the sphere depth equals it at c.z - r = near / d0 (~60)
+    if kind == "depth":
+        hzb.texels[:] = np.uint16(d0.view(np.uint16))
+    else:
+        hzb.texels[:] = np.exp(rng.uniform(np.log(near / 150.0), np.log(near / 5.0), hzb.total)).astype(np.float16).view(np.uint16)
+    sparse = np.array([0, 0, 1, -1, 2, -2, 3, -3, 5, -5, 16, -16, 50, -50, 200, -200, 1000, -1000, 10 ** 4, -10 ** 4, 10 ** 5, -10 ** 5], np.int64)
+
+    def pick_steps(n):
+        # the float64 boundary is a few hundred ulp from where the float32 chains flip (their own rounding noise): half of the
+        # meshlets are spread densely over +-600 ulp -- some land BETWEEN the reference's flip and the fast path's -- the others
+        # take the sparse ladder out to +-10^5
+        dense = rng.integers(-600, 601, n)
+        return np.where(rng.random(n) < 0.5, dense, rng.choice(sparse, n))
+
+    def ulps(x32, k):
+        b = x32.view(np.int32).astype(np.int64)
+        return (b + np.where(b >= 0, k, -k)).astype(np.int32).view(np.float32)
+
+    moved = 0
+    for i in range(len(inst)):
+        W = inst["m_WorldMatrix"][i].astype(np.float64)
+        lod = md["m_MeshLODDatas"][inst["m_MeshDataIdx"][i]][0]
+        b, n = int(lod["m_MeshletDataBufferIdx"]), int(lod["m_NumMeshlets"])
+        sph = ml["m_BoundingSphere"][b:b + n].astype(np.float64)
+        R3 = W[:3, :3]
+        scale = np.sqrt(max(R3[0] @ R3[0], R3[1] @ R3[1], R3[2] @ R3[2]))                          # toyrenderer_common.hlsli:134-140
+        M = (W @ V)[:3, :3]                                                                         # view = [p, 1] W V, then z negated
+        c = np.concatenate([sph[:, :3], np.ones((n, 1))], axis=1) @ W @ V
+        cx, cy, cz = c[:, 0], c[:, 1], -c[:, 2]
+        r = sph[:, 3] * scale
+        Z = cz * cz - r * r
+        ok = (cz > near + r) & (Z > 0) & (rng.random(n) < 0.85)
+        with np.errstate(all="ignore"):
+            vx, vy = np.sqrt(cx * cx + Z), np.sqrt(cy * cy + Z)
+            w = P00 * hw * vx * r / Z                                                               # (maxx - minx) * 0.5 P00 * W, unclamped
+            h = P11 * hh * vy * r / Z
+            m = np.maximum(np.maximum(w, h), 1.0)
+            level = np.minimum(np.floor(np.log2(m)), hzb.mips - 1).astype(np.int64)
+            inside = (np.abs((cx * cz + vx * r) / Z * P00) < 0.98) & (np.abs((cx * cz - vx * r) / Z * P00) < 0.98) & \
+                     (np.abs((cy * cz + vy * r) / Z * P11) < 0.98) & (np.abs((cy * cz - vy * r) / Z * P11) < 0.98)    # no clamp at the screen edge
+        if kind in ("texel_x", "texel_y"):
+            ax = 0 if kind == "texel_x" else 1
+            dim = (np.maximum(hw >> level, 1) if ax == 0 else np.maximum(hh >> level, 1)).astype(np.float64)
+            Pa, ca = (P00, cx) if ax == 0 else (-P11, cy)
+            f = dim * (0.5 + 0.5 * Pa * ca * cz / Z) - 0.5                                          # uv * dim - 0.5 (the two bounds average to c c.z / Z)
+            tgt = np.round(f)
+            c_star = ((tgt + 0.5) / dim - 0.5) * Z / (0.5 * Pa * cz)
+            delta = np.zeros((n, 3)); delta[:, ax] = c_star - ca
+            dp = delta @ np.linalg.inv(M)                                                           # object-space shift with that view-space image
+            take = ok & inside & (np.abs(c_star - ca) < 0.6 * r + 0.05) & np.isfinite(dp).all(axis=1)
+            p_new = (sph[:, :3] + dp).astype(np.float32)
+            j = np.argmax(np.abs(np.linalg.inv(M)[ax]))                                             # the component that moves it most
+            p_new[:, j] = ulps(np.ascontiguousarray(p_new[:, j]), pick_steps(n))
+            ml["m_BoundingSphere"][b:b + n, :3] = np.where(take[:, None], p_new, ml["m_BoundingSphere"][b:b + n, :3])
+        elif kind == "level":
+            # max(w, h) is monotone in r: bisect r (float64) onto the nearest power of two >= 2
+            tgt = np.exp2(np.maximum(np.round(np.log2(np.maximum(m, 1.0))), 1.0))
+            lo_, hi_ = r * 0.25, np.minimum(r * 4.0, cz * 0.45)
+            for _ in range(60):
+                mid = 0.5 * (lo_ + hi_)
+                Zm = cz * cz - mid * mid
+                mm = np.maximum(P00 * hw * np.sqrt(cx * cx + Zm) * mid / Zm, P11 * hh * np.sqrt(cy * cy + Zm) * mid / Zm)
+                big = mm > tgt
+                hi_ = np.where(big, mid, hi_); lo_ = np.where(big, lo_, mid)
+            r_star = 0.5 * (lo_ + hi_)
+            Zs = cz * cz - r_star * r_star
+            reached = np.abs(np.maximum(P00 * hw * np.sqrt(cx * cx + Zs) * r_star / Zs, P11 * hh * np.sqrt(cy * cy + Zs) * r_star / Zs) / tgt - 1.0) < 1e-9
+            take = ok & inside & reached & (tgt <= 2.0 ** (hzb.mips - 1))
+            w_new = ulps((r_star / scale).astype(np.float32), pick_steps(n))
+            ml["m_BoundingSphere"][b:b + n, 3] = np.where(take, w_new, ml["m_BoundingSphere"][b:b + n, 3])
+        else:
+            r_star = cz - near / float(d0)                                                          # nearPlane / (c.z - r) == d0
+            take = ok & (r_star > 0.02) & (r_star < cz / 9.0)
+            w_new = ulps((r_star / scale).astype(np.float32), pick_steps(n))
+            ml["m_BoundingSphere"][b:b + n, 3] = np.where(take, w_new, ml["m_BoundingSphere"][b:b + n, 3])
+        moved += int(take.sum())
+    assert moved > (200 if kind == "depth" else 5000), moved
+    d_cur = synth.gen_depth(view, num_occluders=40, seed=16, scale=3.0)
+    cap = 1 << 19                                                                                   # the footprint-table kernel
+    gs = GpuScene(dev, inst, md, ml, scene.opaqueIds, scene.alphaMaskIds)
+    drv = FrameDriver(dev, gs, view, record_capacity=cap, culling_flags=flags)
+    _upload_hzb(drv, hzb)
+    drv.depth.upload_mip(0, d_cur)
+    try:
+        drv.record()
+        drv.run()
+        got = drv.results()
+        ref = oracle.frame(scene.as_oracle(), view.as_dict(), hzb, d_cur, cullingFlags=flags, maxGroups=cap, record_capacity=cap)
+        _compare_frame(got, ref)
+        assert int(ref.meshletsTested[0]) > (1000 if kind == "depth" else 5000) and 0 < int(ref.drawArgs[0][0]) < int(ref.meshletsTested[0])
+    finally:
+        drv.release()
+        gs.release()

@@ -142,10 +142,10 @@ int main(int argc, char** argv)
 {
     const long millions = argc > 1 ? atol(argv[1]) : 200;
     const long total = millions * 1000000L;
-    long bad = 0, sureN = 0, relevant = 0;
+    long bad = 0, sureN = 0, relevant = 0, anyLevel = 0, anyFoot = 0;
     double worstF = 0, worstM = 0, worstQ = 0;
     static const uint32_t dims[][2] = { { 2048, 2048 }, { 2048, 1024 }, { 4096, 2048 }, { 512, 256 }, { 1024, 1024 } };
-#pragma omp parallel reduction(+ : bad, sureN, relevant) reduction(max : worstF, worstM, worstQ)
+#pragma omp parallel reduction(+ : bad, sureN, relevant, anyLevel, anyFoot) reduction(max : worstF, worstM, worstQ)
     {
         Rng g;
 #ifdef _OPENMP
@@ -200,6 +200,7 @@ int main(int argc, char** argv)
             double q[4];
             const Foot R = reference(c, r, P00, P11, W, H, mips);
             const Foot F = fast(&g, c, r, P00, P11, W, H, mips, &b, &sure, q);
+            if (R.level != F.level) ++anyLevel; else if (R.x0 != F.x0 || R.y0 != F.y0) ++anyFoot;   /* what a build without the bands would get wrong */
             if (!sure) continue;
             ++sureN;
             if (R.level != F.level || R.x0 != F.x0 || R.y0 != F.y0 || R.zx || R.zy) {
@@ -219,6 +220,7 @@ int main(int argc, char** argv)
     }
     printf("%ld samples, %ld with the sphere in front of the near plane, %ld sure (%.3f %% not sure)\n", total, relevant, sureN, 100.0 * (double)(relevant - sureN) / (double)relevant);
     printf("mismatches among the sure lanes: %ld\n", bad);
+    printf("(without the bands: %ld spheres at another level, %ld at another footprint origin)\n", anyLevel, anyFoot);
     printf("largest observed |f - f'| / bound: %.3f;  largest |m - m'| / bound: %.3f\n", worstF, worstM);
     return bad != 0;
 }

@@ -724,10 +724,20 @@ __host__ __device__ inline ProjBands projBands(float P00, float P11, uint32_t hz
     const float d = wBand * 0x1p23f;
     b.mipDelta = d < 0x1p21f ? (uint32_t)d + 1u : 0x200000u;         // (2^21: every lane unsure -- a P or an HZB beyond any use)
     b.mFloor = 1.0f + (float)(b.mipDelta + 4u) * 0x1p-23f;
+#ifdef TR_EXP_PROJ_NOBAND
+    b.mFloor = 1.0f;
+#endif
     return b;
 }
 
-__host__ __device__ inline uint32_t projMipDelta(const ProjBands& b, uint32_t e /* >= 1 */) { return (b.mipDelta >> (e - 1u)) + 4u; }
+__host__ __device__ inline uint32_t projMipDelta(const ProjBands& b, uint32_t e /* >= 1 */)
+{
+#ifdef TR_EXP_PROJ_NOBAND
+    return 0u;
+#else
+    return (b.mipDelta >> (e - 1u)) + 4u;
+#endif
+}
 
 // culling.hlsli:56-62 in closed form, approximately (see above): (minx, miny), (maxx, maxy); `sure` = the preconditions.
 template <bool CZ_BOUNDED /* the caller's own checks already bound c.z (the cone's: c.c <= 2^60) */>

@@ -426,9 +426,51 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
         }
         return 0xFFFFFFFFu;
     };
-    uint32_t s0 = 0, s1 = kCullSteps, sbNext, s0n, s1n;
+    // steps [s0, nSteps) of window sb that hold records for this wave (wave-uniform; 0 = nothing left for it)
+    auto stepsOf = [&](uint32_t sb_, uint32_t s0_, uint32_t s1_) -> uint32_t {
+        if (sb_ == 0xFFFFFFFFu) return 0u;
+        const uint32_t sbBase = sb_ * superSize;
+#ifdef TR_BLOCKED_MAP
+        if (sbBase + waveInTeam * kCullBatch >= G) return 0u;
+        const uint32_t remaining = G - sbBase - waveInTeam * kCullBatch;
+        uint32_t n = (remaining + 1u) / 2u;
+#else
+        if (sbBase + 2 * waveInTeam >= G) return 0u;                                 // nothing left for this wave
+        const uint32_t remaining = G - sbBase - 2 * waveInTeam;
+        uint32_t n = (remaining + 2 * teamWaves - 1) / (2 * teamWaves);
+#endif
+        n = n < kCullSteps ? (n + kRingSlots - 1u) / kRingSlots * kRingSlots : kCullSteps;   // rounded up to whole trips round the ring
+        n = n < s1_ ? n : s1_;                                                       // this team's piece of the window
+        return s0_ < n ? n : 0u;                                                     // (only a piece of the partial last window can be empty)
+    };
+    // PIPELINED BATCHES.  A batch used to begin with three latencies in a row: the drain of the previous batch's last
+    // prefetches, the 64-byte instance blocks of its own records (their addresses come from the list entry), the first two ring
+    // slots (their addresses come from the resolved records) -- 20 % of a wave's cycles outside its step loop for 7 % of its
+    // instructions (profiles/r3/stamps_final_kernel.txt).  Now everything the NEXT batch needs from memory is requested at the
+    // end of the current one, behind its last step: the instance blocks (into registers that live only across the batch
+    // boundary) and, with the tile-ordered list, whose entries carry {first meshlet, count}, the first two ring slots too --
+    // they land in LDS behind the padding prefetches of the last steps, in order.  One wait, in the next prologue, covers the
+    // three.  The list entry of batch n + 1 is made available in prologue n (loaded in prologue n - 1), the one of batch n + 2
+    // requested there.
+#ifndef TR_PIPE
+#define TR_PIPE 1
+#endif
+    constexpr bool kPipe = TR_PIPE != 0 && TR_EARLY_PREFETCH != 0 && kRingSlots == 2;
+    uint32_t s0 = 0, s1 = kCullSteps, sbN, s0N, s1N, sbNN, s0NN, s1NN;
     uint32_t sb = windowOf(0u, s0, s1);
-    uint4 entry = loadEntry(sb);
+    sbN = windowOf(1u, s0N, s1N);
+    uint4 entry = loadEntry(sb), entryN = loadEntry(sbN);
+    auto blockAddr = [&](const uint4& e) -> const float4* {
+#ifdef TR_EXP_INST0     /* experiment, results WRONG: every record reads instance block 0 (what the scattered 64-byte reads cost) */
+        const uint32_t cid = 0u;
+#else
+        const uint32_t cid = e.y < a.numInstances ? e.y : 0u;                        // never read outside the cache (no entry: block 0, unused)
+#endif
+        return a.cache.world + 4ull * cid;                                           // one 64-byte block: world rows + max scale
+    };
+    float4 q0, q1, q2, q3;                                                           // the instance blocks of the batch about to begin (lane l: record l)
+    { const float4* wr = blockAddr(entry); q0 = wr[0]; q1 = wr[1]; q2 = wr[2]; q3 = wr[3]; }
+    bool primed = false;                                                             // wave-uniform: the ring's first two slots were requested at the end of the previous batch
     // ---- DEFERRED MODE (kDeferred: the footprint-table kernel of large passes) ---------------------------------------------
     // The step loop evaluates every meshlet with FAST arithmetic only (cm::stepDeferred: closed-form projection from one
     // v_rsq_f32 per axis and one v_rcp_f32, cone from v_rsq_f32) and, with it, whether the fast values are certain to decide
@@ -499,41 +541,25 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
         __builtin_amdgcn_wave_barrier();
         stCount -= n;
     };
-    for (uint32_t it = 0; sb != 0xFFFFFFFFu; ++it, sb = sbNext, s0 = s0n, s1 = s1n) {
-        sbNext = windowOf(it + 1u, s0n, s1n);
-        const uint32_t sbBase = sb * superSize;
-#ifdef TR_BLOCKED_MAP
-        if (sbBase + waveInTeam * kCullBatch >= G) break;
-        const uint32_t remaining = G - sbBase - waveInTeam * kCullBatch;
-        uint32_t nSteps = (remaining + 1u) / 2u;
-#else
-        if (sbBase + 2 * waveInTeam >= G) break;                                     // nothing left for this wave
-        // steps of this window that still hold records for this wave (wave-uniform), rounded up to whole trips round the ring
-        const uint32_t remaining = G - sbBase - 2 * waveInTeam;
-        uint32_t nSteps = (remaining + 2 * teamWaves - 1) / (2 * teamWaves);
-#endif
-        nSteps = nSteps < kCullSteps ? (nSteps + kRingSlots - 1u) / kRingSlots * kRingSlots : kCullSteps;
-        nSteps = nSteps < s1 ? nSteps : s1;                                          // this team's piece of the window: steps [s0, nSteps)
-        if (s0 >= nSteps) break;                                                     // (only a piece of the partial last window can be empty: the last iteration)
+    for (uint32_t it = 0; sb != 0xFFFFFFFFu; ++it, sb = sbN, s0 = s0N, s1 = s1N, sbN = sbNN, s0N = s0NN, s1N = s1NN) {
+        const uint32_t nSteps = stepsOf(sb, s0, s1);                                 // this team's piece of the window: steps [s0, nSteps)
+        if (nSteps == 0u) break;
+        sbNN = windowOf(it + 2u, s0NN, s1NN);
         TR_STAMP(0);   // between batches
         stAtBatch = stCount;
-        // ---- prologue: lane l resolves its record (basepass.hlsl:52-58) through the instance cull cache: ONE
-        //      level of dependent loads here -- the entry itself was fetched while the previous batch ran ------
+        // ---- prologue: lane l resolves its record (basepass.hlsl:52-58) from its list entry and its instance block, both
+        //      requested a batch ago ---------------------------------------------------------------------------------
         {
             RecordInfo ri;
             ri.lastOff = 0; ri.first = 0;
             const uint4 cur = entry;
-            entry = loadEntry(sbNext);                                               // next batch's entry: in flight during this batch
+            entry = entryN;
+            asm volatile("" : "+v"(entry.x), "+v"(entry.y), "+v"(entry.z), "+v"(entry.w));   // the next batch's entry is AVAILABLE from here on (the compiler's wait for it lands here, where the blocks are waited for anyway)
+            entryN = loadEntry(sbNN);                                                // the entry of the batch after next: in flight during this batch and the next
             const uint32_t g = cur.x < G && (lane >> 1) >= s0 && (lane >> 1) < nSteps ? cur.x : 0xFFFFFFFFu;
             if (lane < kCullBatch) s_gIdx[lane] = g;
             if (g < G) {
-#ifdef TR_EXP_INST0     /* experiment, results WRONG: every record reads instance block 0 (what the scattered 64-byte reads cost) */
-                const uint32_t cid = 0u;
-#else
-                const uint32_t cid = cur.y < a.numInstances ? cur.y : 0u;            // never read outside the cache
-#endif
-                const float4* wr = a.cache.world + 4ull * cid;                       // one 64-byte block: world rows + max scale
-                const float4 q0 = wr[0], q1 = wr[1], q2 = wr[2], q3 = wr[3];
+                const uint32_t cid = cur.y < a.numInstances ? cur.y : 0u;
                 const cm::F3 r0 = { q0.x, q0.y, q0.z }, r1 = { q0.w, q1.x, q1.y }, r2 = { q1.z, q1.w, q2.x };
                 ri.wxy[0] = r0.x; ri.wxy[1] = r0.y; ri.wz[0] = r0.z;
                 ri.wxy[2] = r1.x; ri.wxy[3] = r1.y; ri.wz[1] = r1.z;
@@ -739,14 +765,18 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
         // Prime the ring.  kDefer: a lookup "of the step before the first" (lane 0, entry 0) goes where a step's lookup sits in
         // the load order -- in front of the youngest slot's loads -- so that every step sees the same sequence; its resolve
         // lands in s_mask[0], [1].
+        // (primed: the two slots were requested at the end of the previous batch and have landed -- the prologue's wait covered them;
+        // the first step's deferred resolve then reads the zeros lk0 / lk1 were set to: it lands in s_mask[0], [1] all the same)
+        if (!primed) {
 #pragma unroll
-        for (uint32_t k = 0; k + 1 < kRingSlots; ++k)
-            issueMeshletLoads(ring + kSlotBytes * k, a.stream, s_rec[2 * (s0 + k) + half].first, s_rec[2 * (s0 + k) + half].lastOff, sub16);
-        if (kDefer) {
-            const void* p = TABLE ? (const void*)a.quad.base : (const void*)a.hzb.base;
-            issueLookup(lk0[kRingSlots - 1u], lk1[kRingSlots - 1u], p, p, 0ull);
+            for (uint32_t k = 0; k + 1 < kRingSlots; ++k)
+                issueMeshletLoads(ring + kSlotBytes * k, a.stream, s_rec[2 * (s0 + k) + half].first, s_rec[2 * (s0 + k) + half].lastOff, sub16);
+            if (kDefer) {
+                const void* p = TABLE ? (const void*)a.quad.base : (const void*)a.hzb.base;
+                issueLookup(lk0[kRingSlots - 1u], lk1[kRingSlots - 1u], p, p, 0ull);
+            }
+            issueMeshletLoads(ring + kSlotBytes * (kRingSlots - 1u), a.stream, s_rec[2 * (s0 + kRingSlots - 1u) + half].first, s_rec[2 * (s0 + kRingSlots - 1u) + half].lastOff, sub16);
         }
-        issueMeshletLoads(ring + kSlotBytes * (kRingSlots - 1u), a.stream, s_rec[2 * (s0 + kRingSlots - 1u) + half].first, s_rec[2 * (s0 + kRingSlots - 1u) + half].lastOff, sub16);
 #pragma unroll 1
         for (uint32_t s = s0; s < nSteps; s += kRingSlots) {
             step(std::integral_constant<uint32_t, 0>{}, s);
@@ -758,7 +788,9 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
             else asm volatile("s_waitcnt vmcnt(2)" : "+v"(lk0[kRingSlots - 1u]), "+v"(lk1[kRingSlots - 1u]) :: "memory");
             resolve(2u * nSteps, pVis, pAccept, pPair, pDepth, lk0[kRingSlots - 1u], lk1[kRingSlots - 1u]);
         }
-        TR_WAIT_VMCNT(0);                               // the last (padding) prefetches: nothing may land in the ring later
+        // (not pipelined: the last, padding prefetches must have landed before the next batch primes the ring.  Pipelined: the
+        // next batch's requests go out BEHIND them, below, and land behind them)
+        if (!kPipe) TR_WAIT_VMCNT(0);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (kDeferred && __builtin_expect(batchExact, 0)) {
@@ -788,6 +820,30 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
         {
             const uint32_t g = lane < kCullBatch ? s_gIdx[lane] : 0xFFFFFFFFu;
             if (g < G) a.visMask[g] = s_mask[(lane < kCullBatch ? lane : 0u) + 2u];     // (g is none outside this team's piece of the window)
+        }
+        // ---- the next batch's requests (see PIPELINED BATCHES): its instance blocks, and the ring's first two slots ----------
+        primed = false;
+        const uint32_t nStepsN = stepsOf(sbN, s0N, s1N);
+        if (nStepsN) {
+            const float4* wr = blockAddr(entry);                                     // (entry: the next batch's, available since this batch's prologue)
+            q0 = wr[0]; q1 = wr[1]; q2 = wr[2]; q3 = wr[3];
+            if (kPipe && usePerm) {
+                // {first meshlet, lastOff} of the next batch's record `lane`, exactly as its prologue will resolve them
+                const bool has = entry.x < G && (lane >> 1) >= s0N && (lane >> 1) < nStepsN;
+                uint32_t cnt = entry.w < 32u ? entry.w : 32u;
+                if (!has || (uint64_t)entry.z + cnt > a.numMeshlets) cnt = 0u;
+                const uint32_t pf = cnt ? entry.z : 0u, pl = lastOffOf(cnt);
+                // lane (half, sub) of step s0N + k stages record 2 (s0N + k) + half
+#pragma unroll
+                for (uint32_t k = 0; k < kRingSlots; ++k) {
+                    const int from = (int)((2u * (s0N + k) + half) * 4u);
+                    const uint32_t f = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)pf), l = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)pl);
+                    issueMeshletLoads(ring + kSlotBytes * k, a.stream, f, l, sub16);
+                }
+                primed = true;
+            }
+        } else if (kPipe) {
+            TR_WAIT_VMCNT(0);                                                        // the wave's last batch: nothing of the ring is in flight when it ends
         }
     }
     if (kDeferred && stCount) {
