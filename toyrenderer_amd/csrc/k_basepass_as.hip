@@ -1476,9 +1476,19 @@ void emitListBuild(const trhip::DispatchCtx& ctx, const MeshletCullArgs& a, cons
     emit(p + "scan", [a](hipStream_t s) {
         TRHIP_LAUNCH(visSuperScanKernel, dim3(1), dim3(1024), 0, s, a);
         return trhip::launchStatus("visSuperScanKernel"); });
-    emit(p + "expand", [a, gridSmall](hipStream_t s) {
+    // Experiment (TRHIP_DEFER_EXPAND=1; off): the expansion of a LARGE EARLY pass (122 MB of stores on C3, 26 us) HELD BACK -- it
+    // enters the side stream behind the late meshlet cull (recordASMain flushes it in front of the late list build) instead of
+    // beside the late instance pass and the late meshlet cull.  Measured (profiles/r4/experiments.md): those two drop from 11 +
+    // 30 to 9 + 10 us, but the expansion then runs beside the second HZB build (13 + 5 -> 14 + 17 us), pushes the late list build
+    // and the next frame's table rebuild into the next frame's instance pass (emit 16 -> 25 us): frame 0.470 -> 0.480 ms.  The
+    // stores have to happen somewhere in the 0.13 ms of latency-bound launches around the cull kernel.
+    static const bool deferExpand = [] { const char* e = getenv("TRHIP_DEFER_EXPAND"); return e ? atoi(e) != 0 : false; }();
+    auto expandFn = [a, gridSmall](hipStream_t s) {
         TRHIP_LAUNCH(visExpandKernel, dim3(gridSmall), dim3(kBlock), 0, s, a);
-        return trhip::launchStatus("visExpandKernel"); });
+        return trhip::launchStatus("visExpandKernel"); };
+    if (side && deferExpand && ctx.variant == 0 && prefix[0] == 0)
+        ctx.emitSideHeld("expand", std::move(expandFn), { { a.listGroups ? (const void*)a.listGroups : argsBase, false }, { a.visMask, false }, { a.visibleList, true }, { a.drawArgs, true } });
+    else emit(p + "expand", std::move(expandFn));
 }
 
 template <bool F, bool O, bool C>
@@ -1685,6 +1695,7 @@ int recordASMain(trhip::DispatchCtx& ctx)
         return trhip::launchStatus("meshletCullKernel"); });
     // The side stream costs two events and two cross-stream waits per run (~20 us of host time): worth it
     // when the list build is long (>= 2^19 groups of capacity), not for small passes.
+    ctx.cl->flushHeldSide();                            // (the early pass's held list expansion goes in front of this pass's list build)
     emitListBuild(ctx, a, "", a.recordCapacity >= (1u << 19), ctx.argsBuffer->ptr);
     return TRHIP_OK;
 }

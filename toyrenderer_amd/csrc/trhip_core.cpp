@@ -97,6 +97,15 @@ void DispatchCtx::emitSide(const char* kernelName, std::function<int(hipStream_t
     for (const Op::Access& t : touched) if (t.ptr) cl->ops.back().touched.push_back(t);
 }
 
+void DispatchCtx::emitSideHeld(const char* kernelName, std::function<int(hipStream_t)> fn, std::initializer_list<Op::Access> touched) const
+{
+    if (!cl->dev->sideStream) { emit(kernelName, std::move(fn)); return; }
+    Op op{ std::string(shaderName) + "#" + kernelName, std::move(fn) };
+    op.lane = 1;
+    for (const Op::Access& t : touched) if (t.ptr) op.touched.push_back(t);
+    cl->heldSide.push_back(std::move(op));
+}
+
 } // namespace trhip
 
 using namespace trhip;
@@ -179,6 +188,7 @@ int trhip_device_t::syncAll()
 
 void trhip_cmdlist_t::resetRecording()
 {
+    heldSide.clear();
     ops.clear();
     for (trhip_buffer_t* b : heldBuffers) trhip_buffer_release(b);
     for (trhip_texture_t* t : heldTextures) trhip_texture_release(t);
@@ -623,6 +633,7 @@ int trhip_cmd_close(trhip_cmdlist cl)
     if (!cl) return fail(TRHIP_ERR_INVALID, "cmdlist is null");
     if (!cl->open) return fail(TRHIP_ERR_STATE, "cmd_close: not open");
     if (!cl->markers.empty()) return fail(TRHIP_ERR_STATE, "cmd_close: %zu marker(s) still open", cl->markers.size());
+    cl->flushHeldSide();
     cl->open = false;
     // by command index (a clear merged into an earlier launch is noted against that launch)
     std::stable_sort(cl->useMarks.begin(), cl->useMarks.end(), [](const trhip_cmdlist_t::UseMark& a, const trhip_cmdlist_t::UseMark& b) { return a.op < b.op; });
@@ -638,6 +649,7 @@ int trhip_cmd_close(trhip_cmdlist cl)
 int trhip_cmd_write_buffer(trhip_cmdlist cl, trhip_buffer buf, uint64_t off, const void* src, uint64_t bytes)
 {
     TRHIP_RECORDING(cl);
+    if (buf && cl->heldConflicts(buf->ptr, true)) cl->flushHeldSide();   // (a volatile constant buffer has no memory of its own: never a conflict)
     if (!buf || !src) return fail(TRHIP_ERR_INVALID, "write_buffer: null argument");
     if (off + bytes > buf->byteSize) return fail(TRHIP_ERR_INVALID, "write_buffer(%s): %llu+%llu exceeds %llu bytes", buf->name.c_str(), (unsigned long long)off, (unsigned long long)bytes, (unsigned long long)buf->byteSize);
     if (buf->isVolatileConstant) {
@@ -658,6 +670,7 @@ int trhip_cmd_write_buffer(trhip_cmdlist cl, trhip_buffer buf, uint64_t off, con
 int trhip_cmd_clear_buffer_u32(trhip_cmdlist cl, trhip_buffer buf, uint32_t value)
 {
     TRHIP_RECORDING(cl);
+    if (buf && cl->heldConflicts(buf->ptr, true)) cl->flushHeldSide();
     if (!buf) return fail(TRHIP_ERR_INVALID, "clear_buffer: null buffer");
     if (!buf->ptr) return fail(TRHIP_ERR_STATE, "clear_buffer(%s): no memory bound", buf->name.c_str());
     if (buf->byteSize % 4) return fail(TRHIP_ERR_INVALID, "clear_buffer(%s): size not a multiple of 4", buf->name.c_str());
@@ -673,6 +686,7 @@ int trhip_cmd_clear_buffer_u32(trhip_cmdlist cl, trhip_buffer buf, uint32_t valu
 int trhip_cmd_clear_texture_f32(trhip_cmdlist cl, trhip_texture tex, float value)
 {
     TRHIP_RECORDING(cl);
+    if (tex && cl->heldConflicts(tex->ptr, true)) cl->flushHeldSide();
     if (!tex) return fail(TRHIP_ERR_INVALID, "clear_texture: null texture");
     if (!tex->ptr) return fail(TRHIP_ERR_STATE, "clear_texture(%s): no memory bound", tex->name.c_str());
     void* p = tex->ptr;
@@ -697,6 +711,7 @@ int trhip_cmd_clear_texture_f32(trhip_cmdlist cl, trhip_texture tex, float value
 int trhip_cmd_copy_buffer(trhip_cmdlist cl, trhip_buffer dst, uint64_t dstOff, trhip_buffer src, uint64_t srcOff, uint64_t bytes)
 {
     TRHIP_RECORDING(cl);
+    cl->flushHeldSide();                               // (held side ops: nothing is assumed about what this command touches)
     if (!dst || !src) return fail(TRHIP_ERR_INVALID, "copy_buffer: null buffer");
     if (!dst->ptr || !src->ptr) return fail(TRHIP_ERR_STATE, "copy_buffer: a buffer has no memory bound");
     if (dstOff + bytes > dst->byteSize || srcOff + bytes > src->byteSize) return fail(TRHIP_ERR_INVALID, "copy_buffer(%s <- %s): range exceeds a buffer", dst->name.c_str(), src->name.c_str());
@@ -711,6 +726,7 @@ int trhip_cmd_copy_buffer(trhip_cmdlist cl, trhip_buffer dst, uint64_t dstOff, t
 int trhip_cmd_host_callback(trhip_cmdlist cl, trhip_host_fn fn, void* user)
 {
     TRHIP_RECORDING(cl);
+    cl->flushHeldSide();                               // (held side ops: nothing is assumed about what this command touches)
     if (!fn) return fail(TRHIP_ERR_INVALID, "host_callback: null function");
     cl->ops.push_back({ "", [fn, user](hipStream_t s) { fn(user, (void*)s); return (int)TRHIP_OK; } });
     cl->ops.back().kind = "host_callback";
@@ -720,6 +736,7 @@ int trhip_cmd_host_callback(trhip_cmdlist cl, trhip_host_fn fn, void* user)
 int trhip_cmd_copy_texture(trhip_cmdlist cl, trhip_texture dst, trhip_texture src)
 {
     TRHIP_RECORDING(cl);
+    cl->flushHeldSide();                               // (held side ops: nothing is assumed about what this command touches)
     if (!dst || !src) return fail(TRHIP_ERR_INVALID, "copy_texture: null texture");
     if (!dst->ptr || !src->ptr) return fail(TRHIP_ERR_STATE, "copy_texture: a texture has no memory bound");
     if (dst->width != src->width || dst->height != src->height || dst->mips != src->mips || dst->format != src->format)
@@ -741,6 +758,20 @@ static int recordDispatch(trhip_cmdlist cl, const char* name, const trhip_bindin
     const ShaderEntry* e = findShader(name);
     if (!e) return fail(TRHIP_ERR_UNKNOWN_SHADER, "dispatch: unknown shader '%s'", name);
     if (nb && !b) return fail(TRHIP_ERR_INVALID, "dispatch(%s): bindings is null", name);
+    if (!cl->heldSide.empty()) {                        // a held side op that touches one of this command's resources goes first
+        bool conflict = indirect && args && cl->heldConflicts(args->ptr, false);
+        for (uint32_t i = 0; i < nb && !conflict; ++i) {
+            if (!b[i].resource) continue;
+            switch (b[i].type) {
+            case TRHIP_BIND_CONSTANT_BUFFER: case TRHIP_BIND_STRUCTURED_SRV: case TRHIP_BIND_STRUCTURED_UAV:
+                conflict = cl->heldConflicts(((trhip_buffer_t*)b[i].resource)->ptr, b[i].type == TRHIP_BIND_STRUCTURED_UAV); break;
+            case TRHIP_BIND_TEXTURE_SRV: case TRHIP_BIND_TEXTURE_UAV:
+                conflict = cl->heldConflicts(((trhip_texture_t*)b[i].resource)->ptr, b[i].type == TRHIP_BIND_TEXTURE_UAV); break;
+            default: break;
+            }
+        }
+        if (conflict) cl->flushHeldSide();
+    }
     if (indirect) {
         if (!args || !args->ptr) return fail(TRHIP_ERR_INVALID, "dispatch_indirect(%s): no argument buffer", name);
         if (argsOff % 4 || argsOff + 12 > args->byteSize) return fail(TRHIP_ERR_INVALID, "dispatch_indirect(%s): bad argument offset %u", name, argsOff);

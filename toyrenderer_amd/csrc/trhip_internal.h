@@ -231,6 +231,28 @@ struct trhip_cmdlist_t
     // use marks of both stay attached to it).  Cleared by any other command.
     struct Peephole { size_t op = SIZE_MAX; const char* kind = nullptr; std::shared_ptr<void> data; } peephole;
 
+    // HELD side ops: a side-stream op whose results nothing in this recording needs may be held back and put into the stream
+    // LATER than where it was recorded -- behind the next command that forks the side stream anyway -- so that it overlaps a
+    // different part of the frame (the early pass's list expansion, 122 MB of stores on C3, ran beside the latency-bound late
+    // phase and tripled its kernels' times).  It is flushed, i.e. appended at the current position, before any command that uses
+    // a resource it touches (recordDispatch, clears, copies check their operands), by whoever wants it in front of its own side
+    // ops, and when the recording is closed.
+    std::vector<trhip::Op> heldSide;
+    bool heldConflicts(const void* ptr, bool write) const
+    {
+        for (const trhip::Op& op : heldSide)
+            for (const trhip::Op::Access& t : op.touched)
+                if (t.ptr == ptr && (t.write || write)) return true;
+        return false;
+    }
+    void flushHeldSide()
+    {
+        if (heldSide.empty()) return;
+        for (trhip::Op& op : heldSide) ops.push_back(std::move(op));
+        heldSide.clear();
+        openClearBatch.reset(); openClearOp = SIZE_MAX;
+        peephole = Peephole{};
+    }
     void* scratchAlloc(size_t bytes);       // device memory valid until the list is re-opened/released
     void* scratchAllocSide(size_t bytes);   // same, from an arena only side-stream ops use (they are in order among themselves)
     std::vector<ScratchBlock> sideScratch;
@@ -266,6 +288,8 @@ struct DispatchCtx
     // Same, on the device's side stream, ordered after everything recorded before it.  `touched`: every
     // device allocation the op reads or writes that a later command could also use (base pointers).
     void emitSide(const char* kernelName, std::function<int(hipStream_t)> fn, std::initializer_list<Op::Access> touched) const;
+    // Same, HELD (trhip_cmdlist_t::heldSide): enters the stream at the next flush, not here.
+    void emitSideHeld(const char* kernelName, std::function<int(hipStream_t)> fn, std::initializer_list<Op::Access> touched) const;
 };
 
 // Footprint-min table of an HZB (trhip_texture_t::quad), k_hzb.hip.  ensure: allocate + lay out (record time);
