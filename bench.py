@@ -202,6 +202,8 @@ def main():
         nodes, prim_to_node = synth.animated_nodes(spec, 0)
         r.load_nodes(nodes, prim_to_node)              # uploaded with the first frame, then resident
         del nodes
+        if shard_world > 1:
+            r.set_instance_update_range(i0, i1 - i0)   # a rank rebuilds the transforms of its own shard, not of the replicated table
     r.set_culling(args.flags)
     r.set_gpu_timers(False)          # the per-renderer timer queries are instrumentation (2 timestamp packets each)
     r.upload_depth(depth)

@@ -40,6 +40,10 @@ int  trhost_upload_meshlets(uint64_t first_meshlet, const void* meshlets, uint64
 /* Node hierarchy for UpdateInstanceConstsRenderer (BasePassRenderers.cpp:64-104); enables the pass. */
 int  trhost_load_nodes(const void* node_local_transforms, uint32_t num_nodes, const uint32_t* primitive_to_node);
 int  trhost_set_node_transforms(const void* node_local_transforms, uint32_t num_nodes);
+/* Multi-GPU (not in the reference, which updates every instance it renders): UpdateInstanceConstsRenderer rebuilds the
+ * transforms of instances [first, first + count) only -- the range a rank's id lists cover; the rest of the replicated
+ * instance table is never read by its passes.  Default: the whole table. */
+int  trhost_set_instance_update_range(uint32_t first, uint32_t count);
 
 /* View (Scene.cpp:109-145): row-major 4x4, row vectors.  prev_world_to_view / view_to_clip may be NULL
  * (previous = last frame's; projection = RH reverse-Z infinite from fov/aspect/near). */

@@ -235,6 +235,23 @@ def test_update_instance_consts(dev, oracle):
     ref = inst.copy()
     oracle.update_instance_consts(nodes, prim, ref); oracle.update_instance_consts(nodes, prim, ref)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    # the same pass over a RANGE of the table (this build's second push-constant word, { count, first }: what a rank of a sharded
+    # scene dispatches -- trhost_set_instance_update_range): the range follows the oracle, everything else keeps its bytes
+    for first, count in ((0, 1), (1, 255), (257, 256), (700, 1300), (1999, 1)):
+        b_inst.upload(inst)
+        cl2 = dev.create_command_list()
+        cl2.open()
+        cl2.dispatch("updateinstanceconsts_CS_UpdateInstanceConstsAndBuildTLAS",
+                     [rhi.PUSH(0), rhi.SRV(0, b_nodes), rhi.SRV(1, b_prim), rhi.UAV(0, b_inst)], ((count + 31) // 32, 1, 1), push=np.array([count, first], np.uint32))
+        cl2.close()
+        dev.execute(cl2)
+        got = b_inst.download(I.BasePassInstanceConstants)
+        ref = inst.copy()
+        part = inst[first:first + count].copy()
+        oracle.update_instance_consts(nodes, prim[first:first + count], part)
+        ref[first:first + count] = part
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (first, count)
+        cl2.release()
     cl.release(); b_nodes.release(); b_prim.release(); b_inst.release()
 
 

@@ -8,6 +8,7 @@
 #                                 launch order (first 12, every 16th, last 12) + per-kernel averages of the steady-state launches
 #   pmc <name> "<group>" ...      one rocprofv3 --pmc pass per counter group on <name>
 #   events                        per-launch HIP-event durations of the dominant kernel in launch order (tools/events_order.py)
+#   emul M [bench args]           rank 0's share at M emulated ranks: without / with the exchange / with the loop-back collective
 #   bench [bench args]            the plain bench line -> gpurun_out/r4/bench*.json
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 LIB=$R/toyrenderer_amd/lib
@@ -51,6 +52,16 @@ pmc)
 events)
   use ${1:-base}
   python3 $R/tools/events_order.py 2>$OUT/events.err | tee -a $OUT/events.txt ;;
+emul)
+  # rank 0's share at M emulated ranks: no exchange / exchange with a 1-rank RCCL group / loop-back collective (real unpack volume)
+  M=${1:-8}; shift || true
+  use base
+  for mode in none one loop; do
+    case $mode in none) E="TR_NO_GATHER=1";; one) E="";; loop) E="TR_EMULATE_LOOPBACK=1";; esac
+    env $E python3 $R/bench.py --emulate-ranks $M --steps 100 --warmup 10 --no-cpu-baseline --no-profile "$@" 2>$OUT/emul_$mode.err | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('${LABEL:-emul} M $M', '$mode', 'ms', d['ms_per_step'], 'Gm/s(rank)', d['value'])" | tee -a $OUT/emul.txt
+  done ;;
 bench)
   use base
   python3 $R/bench.py "$@" 2>$OUT/bench.err | tee $OUT/bench_$(date +%H%M%S).json ;;

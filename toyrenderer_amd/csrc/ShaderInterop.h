@@ -177,6 +177,13 @@ struct UpdateInstanceConstsPassConstants
 {
     uint32_t m_NumInstances;
 };
+// this build's extension (not in the reference): the same pass over the instance range [m_FirstInstance, + m_NumInstances) --
+// a rank of a sharded scene updates the instances it culls (csrc/host/BasePassRenderers.cpp, Scene::m_InstanceUpdate*)
+struct UpdateInstanceConstsShardConstants
+{
+    uint32_t m_NumInstances;
+    uint32_t m_FirstInstance;
+};
 
 // FFXHelpers.cpp:15-23 (push constants of the SPD pass)
 struct SPDConstants

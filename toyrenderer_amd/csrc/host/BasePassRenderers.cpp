@@ -113,9 +113,13 @@ public:
             commandList->writeBuffer(g_Scene->m_NodeLocalTransformsBuffer, g_Scene->m_NodeLocalTransforms.data(), g_Scene->m_NodeLocalTransforms.size());
             g_Scene->m_bNodeLocalTransformsDirty = false;
         }
-        const uint32_t numPrimitives = g_Scene->m_NumPrimitives;
-        UpdateInstanceConstsPassConstants passConstants;
+        // (multi-GPU: a rank updates the instances it culls -- Scene::m_InstanceUpdateFirst / Count, the whole table by default)
+        const uint32_t first = std::min(g_Scene->m_InstanceUpdateFirst, g_Scene->m_NumPrimitives);
+        const uint32_t numPrimitives = std::min(g_Scene->m_InstanceUpdateCount, g_Scene->m_NumPrimitives - first);
+        if (numPrimitives == 0) return;
+        UpdateInstanceConstsShardConstants passConstants;
         passConstants.m_NumInstances = numPrimitives;
+        passConstants.m_FirstInstance = first;
 
         nvrhi::BindingSetDesc bindingSetDesc;                                 // :137-145 (u1 = TLAS descriptors: ray tracing, out of scope)
         bindingSetDesc.bindings = {

@@ -64,6 +64,9 @@ public:
     bool m_bFreezeCullingCamera = false;
     int32_t m_ForceMeshLOD = -1;
     bool m_bUpdateInstanceTransforms = false;        // run UpdateInstanceConstsRenderer (animated scenes)
+    // multi-GPU (not in the reference): the instances whose transforms this rank updates every frame -- the contiguous range its
+    // id lists cover (trhost_set_instance_update_range); the whole (replicated) table by default
+    uint32_t m_InstanceUpdateFirst = 0, m_InstanceUpdateCount = 0xFFFFFFFFu;
 
     uint32_t m_NumPrimitives = 0;
     std::vector<uint32_t> m_OpaquePrimitiveIDs, m_AlphaMaskPrimitiveIDs;

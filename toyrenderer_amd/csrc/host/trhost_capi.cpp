@@ -130,6 +130,11 @@ int trhost_set_node_transforms(const void* node_local_transforms, uint32_t num_n
     });
 }
 
+int trhost_set_instance_update_range(uint32_t first, uint32_t count)
+{
+    return guarded([&] { g_Scene->m_InstanceUpdateFirst = first; g_Scene->m_InstanceUpdateCount = count; });
+}
+
 int trhost_set_camera(const float* world_to_view, const float* prev_world_to_view, const float* view_to_clip, float near_plane)
 {
     return guarded([&] {

@@ -70,14 +70,15 @@ static_assert(sizeof(BasePassInstanceConstants) % 16 == 0 && offsetof(BasePassIn
 
 __global__ __launch_bounds__(kUpdBlock) void updateInstanceConstsKernel(const NodeLocalTransform* __restrict__ nodes, uint32_t numNodes,
                                                                         const uint32_t* __restrict__ primToNode,
-                                                                        BasePassInstanceConstants* instances, uint32_t n,
+                                                                        BasePassInstanceConstants* instances, uint32_t first, uint32_t n,
                                                                         bool refreshCache, InstanceCullCache cache)
 {
     __shared__ float4 s_rec[kUpdBlock * kRecVec];                                // the block's instance records
     __shared__ float4 s_world[kUpdBlock * 4];                                    // the block's cull-cache world blocks
     const uint32_t tid = threadIdx.x;
-    const uint32_t i0 = blockIdx.x * kUpdBlock;
-    const uint32_t cnt = n - i0 < kUpdBlock ? n - i0 : kUpdBlock;                // (the grid covers [0, n))
+    const uint32_t b0 = blockIdx.x * kUpdBlock;
+    const uint32_t cnt = n - b0 < kUpdBlock ? n - b0 : kUpdBlock;                // (the grid covers the n instances [first, first + n))
+    const uint32_t i0 = first + b0;
     const uint32_t i = i0 + tid;
     const bool mine = tid < cnt;
     // requests first: the node id (and, behind it, the node), the block's records
@@ -146,15 +147,22 @@ __global__ __launch_bounds__(kUpdBlock) void updateInstanceConstsKernel(const No
 int recordUpdateInstanceConsts(trhip::DispatchCtx& ctx)
 {
     // BasePassRenderers.cpp:134-151
-    const UpdateInstanceConstsPassConstants* k = (const UpdateInstanceConstsPassConstants*)ctx.constants(0, sizeof(UpdateInstanceConstsPassConstants));
-    TRHIP_REQUIRE(k, "%s: push constants (UpdateInstanceConstsPassConstants) missing", ctx.shaderName);
+    // the reference's constants are { m_NumInstances }; a second word, { m_NumInstances, m_FirstInstance } (this build's host
+    // side, sharded scenes: a rank updates the instances it culls, not the whole replicated table), moves the range
+    const UpdateInstanceConstsShardConstants* ks = (const UpdateInstanceConstsShardConstants*)ctx.constants(0, sizeof(UpdateInstanceConstsShardConstants));
+    UpdateInstanceConstsShardConstants kk = { 0u, 0u };
+    if (ks) kk = *ks;
+    else if (const UpdateInstanceConstsPassConstants* k1 = (const UpdateInstanceConstsPassConstants*)ctx.constants(0, sizeof(UpdateInstanceConstsPassConstants))) kk.m_NumInstances = k1->m_NumInstances;
+    else TRHIP_REQUIRE(false, "%s: push constants (UpdateInstanceConstsPassConstants) missing", ctx.shaderName);
+    const UpdateInstanceConstsShardConstants* k = &kk;
+    const uint32_t first = kk.m_FirstInstance;
     trhip_buffer_t* nodes = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 0);
     trhip_buffer_t* primToNode = ctx.buffer(TRHIP_BIND_STRUCTURED_SRV, 1);
     trhip_buffer_t* instances = ctx.buffer(TRHIP_BIND_STRUCTURED_UAV, 0);
     TRHIP_REQUIRE(nodes && primToNode && instances, "%s: needs SRVs t0 (nodes), t1 (prim->node) and UAV u0 (instances)", ctx.shaderName);
     TRHIP_REQUIRE(nodes->byteSize % sizeof(NodeLocalTransform) == 0, "%s: node buffer size is not a multiple of 48", ctx.shaderName);
-    TRHIP_REQUIRE((uint64_t)k->m_NumInstances * 4 <= primToNode->byteSize, "%s: m_NumInstances exceeds the prim->node buffer", ctx.shaderName);
-    TRHIP_REQUIRE((uint64_t)k->m_NumInstances * sizeof(BasePassInstanceConstants) <= instances->byteSize, "%s: m_NumInstances exceeds the instance buffer", ctx.shaderName);
+    TRHIP_REQUIRE(((uint64_t)first + k->m_NumInstances) * 4 <= primToNode->byteSize, "%s: the instance range exceeds the prim->node buffer", ctx.shaderName);
+    TRHIP_REQUIRE(((uint64_t)first + k->m_NumInstances) * sizeof(BasePassInstanceConstants) <= instances->byteSize, "%s: the instance range exceeds the instance buffer", ctx.shaderName);
     TRHIP_REQUIRE(!ctx.indirect, "%s: dispatched directly", ctx.shaderName);
     const uint64_t threads = (uint64_t)ctx.gx * kNumThreadsPerWave;
     const uint32_t n = threads < k->m_NumInstances ? (uint32_t)threads : k->m_NumInstances;
@@ -173,7 +181,7 @@ int recordUpdateInstanceConsts(trhip::DispatchCtx& ctx)
                              instances->cullCacheBytes >= (instances->byteSize / sizeof(BasePassInstanceConstants)) * kInstanceCacheBytesPerInstance &&
                              !getenv("TRHIP_NO_CACHE_REFRESH");
         const InstanceCullCache cache = refresh ? instanceCacheLayout(instances->cullCache, instances->byteSize / sizeof(BasePassInstanceConstants)) : InstanceCullCache{};
-        TRHIP_LAUNCH(updateInstanceConstsKernel, dim3((n + kUpdBlock - 1) / kUpdBlock), dim3(kUpdBlock), 0, s, np, numNodes, pn, ip, n, refresh, cache);
+        TRHIP_LAUNCH(updateInstanceConstsKernel, dim3((n + kUpdBlock - 1) / kUpdBlock), dim3(kUpdBlock), 0, s, np, numNodes, pn, ip, first, n, refresh, cache);
         if (refresh) instances->cullCacheInstVersion = now;
         return trhip::launchStatus("updateInstanceConstsKernel"); });
     return TRHIP_OK;

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtoyrenderer_host.so")
 
 HOST_SYMBOLS = [
     "trhost_last_error", "trhost_initialize", "trhost_shutdown", "trhost_load_scene", "trhost_upload_meshlets", "trhost_load_nodes",
-    "trhost_set_node_transforms", "trhost_set_camera", "trhost_set_culling", "trhost_set_limits", "trhost_upload_depth",
+    "trhost_set_node_transforms", "trhost_set_instance_update_range", "trhost_set_camera", "trhost_set_culling", "trhost_set_limits", "trhost_upload_depth",
     "trhost_upload_hzb_mip", "trhost_download_hzb_mip", "trhost_hzb_info", "trhost_frame", "trhost_wait_idle",
     "trhost_pass_buffers", "trhost_instance_buffer", "trhost_device", "trhost_render_graph_stats", "trhost_renderer_times",
     "trhost_heap_sim", "trhost_set_shard_late_exchange", "trhost_set_gpu_timers",
@@ -69,6 +69,7 @@ def load() -> C.CDLL:
     L.trhost_upload_meshlets.argtypes = [u64, vp, u64]
     L.trhost_load_nodes.argtypes = [vp, u32, vp]
     L.trhost_set_node_transforms.argtypes = [vp, u32]
+    L.trhost_set_instance_update_range.argtypes = [u32, u32]
     L.trhost_set_camera.argtypes = [vp, vp, vp, C.c_float]
     L.trhost_set_culling.argtypes = [C.c_int] * 5
     L.trhost_set_limits.argtypes = [u32, u64]
@@ -170,6 +171,10 @@ class Renderer:
     def set_node_transforms(self, nodes):
         n = np.ascontiguousarray(nodes)
         _check(load().trhost_set_node_transforms(n.ctypes.data, len(n)))
+
+    def set_instance_update_range(self, first: int, count: int):
+        """Multi-GPU: the per-frame transform update covers instances [first, first + count) only (this rank's shard)."""
+        _check(load().trhost_set_instance_update_range(int(first), int(count)))
 
     def set_camera(self, view):
         w = np.ascontiguousarray(view.worldToView, np.float32); p = np.ascontiguousarray(view.prevWorldToView, np.float32)
