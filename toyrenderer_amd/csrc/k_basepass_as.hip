@@ -12,26 +12,29 @@
 // across groups (the canonical order of SURVEY.md section 7).  LATE_CULL is unused by the
 // reference's AS (Q5), so both permutations are the same kernel.
 //
-// This is the hot kernel of the path (32 B of MeshletData per meshlet tested).  Structure for
-// CDNA4 (DESIGN.md section 5 has the measurements behind each point):
-//   * a workgroup (4 waves) walks WINDOWS of 120 consecutive records of the tile-ordered list; a wave owns a BATCH of 30
-//     of them (no workgroup barriers in the loop): lane l resolves record l -- one level of dependent loads: the
-//     16-byte entry {record, instance, first meshlet, count} the instance pass wrote (fetched a batch ahead), then
-//     the instance's 64-byte block of the cull cache (instance_cache.hip.h) -- computes the adjugate and parks 96 B of
-//     per-record invariants in the wave's private LDS slice, (x, y) pairs first;
-//   * main loop, 15 steps: two records per step (lanes 0-31 / 32-63), per-record data are LDS broadcast reads; the
-//     MeshletData of a step (2 x 1 KB) goes from memory straight into a 3-slot LDS ring (global_load_lds_dwordx4, each
-//     cache line requested once), three steps ahead, and every lane reads ITS OWN meshlet from there; the ring's loads,
-//     the HZB lookup and their waits are hand-counted inline assembly (issueMeshletLoads below);
-//   * every test is evaluated branch-free and the result is the AND (the tests are pure, so this equals the
-//     reference's short-circuit order :73-108); transforms, projection halves, 3x3 products and the cone decode run as
-//     packed fp32 pairs, and all square roots and divisions of a step go through cm::stepQuotients: exact IEEE results
-//     without the v_div_scale / v_div_fmas / v_div_fixup glue whenever the whole wave's operands allow it;
-//   * the HZB lookup is ONE 2-byte load from the footprint-min table (k_hzb.hip, 8 x 8 blocks), only for lanes still
-//     in the race; the rare lookups the table cannot serve are deferred to the texel path and patched into the batch's
-//     masks while those are still in LDS;
-//   * the loop issues no stores: the 30 masks of a batch (WaveActiveCountBits/WavePrefixCountBits :116-120 = the two
-//     halves of the ballot) are staged in LDS and leave in one store.
+// This is the hot kernel of the path (32 B of MeshletData per meshlet tested).  The kernel as shipped
+// (DESIGN.md section 5 has the measurements behind each point; what was tried on the way is in profiles/r*/experiments.md):
+//   * persistent grid, 5 workgroups of 4 waves per CU.  A workgroup walks WINDOWS of 128 consecutive records of the tile-
+//     ordered list the instance pass wrote; a wave owns a BATCH of 32 of them (no workgroup barrier in the loop): lane l
+//     resolves record l from its 16-byte list entry {record, instance, first meshlet, count} and the instance's 64-byte
+//     block of the cull cache (instance_cache.hip.h), computes the adjugate and parks 96 B of per-record invariants in the
+//     wave's LDS slice.  Entry and block are requested a batch ahead (PIPELINED BATCHES below);
+//   * step loop, 16 steps: two records per step (lanes 0-31 / 32-63), per-record data are LDS broadcast reads.  The kernel
+//     streams the MESHLET CULL STREAM (MeshletCullStream: the 20 bytes per meshlet the cull reads, as two dense arrays):
+//     one global_load_lds_dwordx4 + one global_load_lds_dword per step, whole lines, each requested once, into a 2-slot
+//     ring in LDS, refilled at the top of the step; every lane reads ITS OWN meshlet from there.  The ring's loads, the HZB
+//     lookup and their waits are hand-counted inline assembly (issueMeshletLoads; tools/check_inflight.py lints them);
+//   * every test is evaluated branch-free and the result is the AND (the tests are pure, so this equals the reference's
+//     short-circuit order :73-108); predicates are lane masks straight from the vector compares;
+//   * footprint-table kernel (TABLE: large early passes) = DEFERRED MODE: projection and cone from v_rsq_f32 / v_rcp_f32
+//     with proven bands (cm::projectFiltered, cm::coneBackSure); the HZB lookup is ONE 2-byte load from the footprint-min
+//     table (hzb_quad.hip.h), consumed a step later; a lane whose fast values are not certain to decide what the reference
+//     decides goes on the wave's list in LDS and is re-evaluated exactly, 32-64 lanes at a time, at batch boundaries;
+//   * texel kernel (small passes, late passes, the deferred mode's last resort): cm::stepQuotients -- the exact IEEE square
+//     roots and divisions without the v_div_scale / v_div_fmas / v_div_fixup glue whenever the whole wave's operands allow
+//     it -- and two texel-pair loads per lookup;
+//   * the loop issues no stores: the 32 masks of a batch (WaveActiveCountBits / WavePrefixCountBits :116-120 = the two
+//     halves of the ballot) are staged in LDS and leave in one store per wave and batch.
 #include <algorithm>
 #include <cstdlib>
 #include <string>
@@ -66,6 +69,9 @@ constexpr uint32_t kSteps = kBatch / 2;          // two records per wave step
 /* records per wave and prologue: a multiple of 2 * TR_RING_SLOTS.  Measured on C3 with 2 ring slots: 64 records (47 KB of
  * LDS per workgroup, 3 workgroups per CU) 0.511 ms, 32 (34 KB, 4 per CU) 0.482 ms, 16 (5 per CU) 0.498 ms. */
 #define TR_CULL_BATCH (TR_RING_SLOTS == 3 ? 30 : 32)
+#endif
+#ifndef TR_WINDOW_MAP
+#define TR_WINDOW_MAP 0      /* see windowOf */
 #endif
 #ifndef TR_EARLY_PREFETCH
 /* 1: a step refills its ring slot as soon as it has read its own meshlets out of it (the top of the step) instead of
@@ -320,7 +326,7 @@ __device__ __forceinline__ bool exactMeshletVisible(const MeshletCullArgs& a, co
 #define TR_LK_POLICY " sc1 nt"
 #endif
 #ifndef TR_CULL_WAVES_PER_EU
-#define TR_CULL_WAVES_PER_EU 5   /* waves per SIMD the register allocation aims at (96 VGPRs; the full-flags table kernel spills five dwords outside its loop) = workgroups of 27.3 KB LDS per CU.  With the 32-byte records staged (rounds 2-3) 4, 5 and 6 per CU ran alike; with the 20-byte stream the kernel is closer to its issue time and 5 is 2.3 % faster than 4 */
+#define TR_CULL_WAVES_PER_EU 5   /* waves per SIMD the register allocation aims at (96 VGPRs; a few dwords spilled outside the loop) = workgroups of <= 32 000 B LDS per CU.  With the 32-byte records staged (rounds 2-3) 4, 5 and 6 per CU ran alike; with the 20-byte stream 5 is 2.3 % faster than 4, and the deferred mode at 4 per CU (LDS 32 720 B) ran 11 % slower than at 5 */
 #endif
 template <bool FRUSTUM, bool OCCLUSION, bool CONE, bool TABLE>
 __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullKernel(MeshletCullArgs a)
@@ -418,7 +424,21 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
     // iteration `it` of this team: window (0xFFFFFFFF = none) and the steps [s0, s1) of it
     auto windowOf = [&](uint32_t it, uint32_t& s0, uint32_t& s1) -> uint32_t {
         s0 = 0u; s1 = kCullSteps;
-        if (it < fullRounds) { const uint64_t w = (uint64_t)it * teams + team; return w < numSuper ? (uint32_t)w : 0xFFFFFFFFu; }
+        if (it < fullRounds) {
+            // Which window: the workgroups that share a CU (the dispatcher deals workgroups b, b + CUs, b + 2 CUs ... onto the same
+            // CU while the grid is CUs x TR_CULL_WAVES_PER_EU) take ADJACENT windows of the tile-ordered list -- the same screen
+            // region, the same few hundred lines of the footprint table in the CU's L1 (TR_WINDOW_MAP 1: adjacent in every round;
+            // 2: a CU keeps one contiguous range of the list for its whole life; 0: round-robin over all workgroups, rounds 1-3)
+            uint64_t w = (uint64_t)it * teams + team;
+#if TR_WINDOW_MAP
+            constexpr uint32_t kCo = TR_CULL_WAVES_PER_EU;
+            if (teams % kCo == 0u) {
+                const uint32_t perRow = teams / kCo, c = team % perRow, j = team / perRow;
+                w = TR_WINDOW_MAP == 2 ? ((uint64_t)c * fullRounds + it) * kCo + j : (uint64_t)it * teams + (uint64_t)c * kCo + j;
+            }
+#endif
+            return w < numSuper ? (uint32_t)w : 0xFFFFFFFFu;
+        }
         if (it == fullRounds && left && team < left * piecesPer) {
             s0 = (team % piecesPer) * stepsPer;
             s1 = std::min(s0 + stepsPer, kCullSteps);
@@ -1643,8 +1663,8 @@ int recordASMain(trhip::DispatchCtx& ctx)
 
     // Persistent grid: the group count lives on the device (indirect), so launch enough
     // workgroups to fill the chip and let them stride over the chunks.
-    // As many workgroups per CU as the LDS allows (39.5 KB each: 13.5 KB of per-record data + 24 KB of staged MeshletData):
-    // the kernel's pace is set by the bytes it keeps in flight (3 ring slots x 2 KB per wave), see issueMeshletLoads.
+    // Five workgroups per CU: 31.7 KB of LDS each (13.8 KB of per-record data, 10 KB of ring, 5 KB of deferred list) and 96
+    // VGPRs.  (LDS: the allocation granule makes 32 000 bytes the limit for five -- 32 720 ran four per CU, 11 % slower.)
     uint32_t blocksPerCU = TR_CULL_WAVES_PER_EU;
     if (const char* e = getenv("TRHIP_AS_BLOCKS_PER_CU")) blocksPerCU = (uint32_t)atoi(e) ? (uint32_t)atoi(e) : blocksPerCU;   // tuning experiments
     uint32_t grid = ctx.computeUnits() * blocksPerCU;

@@ -16,6 +16,7 @@
 // scratch per entry (A write, C read), 12 B per record (C).  Bound: HBM; the pass is <5 % of a
 // frame on the 100 M-meshlet config (DESIGN.md "Kernels").
 #include "cull_math.hip.h"
+#include "hzb_quad.hip.h"
 #include "instance_cache.hip.h"
 #include "trhip_internal.h"
 
@@ -71,7 +72,7 @@ struct InstanceCullArgs
 };
 
 // What an early recordGPUCulling leaves for a recordBuildLateArgs that follows it immediately (trhip_cmdlist_t::peephole).
-struct EarlyCullNote { InstanceCullArgs a; size_t scanOp; bool fused; };
+struct EarlyCullNote { InstanceCullArgs a; size_t scanOp; bool fused; trhip_texture_t* quadOwner = nullptr; };
 
 __global__ __launch_bounds__(256) void instanceCacheKernel(const BasePassInstanceConstants* instances, uint32_t n,
                                                            const MeshData* meshData, uint32_t numMeshes, InstanceCullCache c)
@@ -545,8 +546,17 @@ constexpr uint32_t kFusedStatusStride = 16;                          // 64-bit w
 constexpr unsigned long long kFusedFlag = 1ull << 63, kFusedPoison = 1ull << 60;
 
 template <int LATE>
-__global__ __launch_bounds__(kBlock) void instanceFusedKernel(InstanceCullArgs a)
+__global__ __launch_bounds__(kBlock) void instanceFusedKernel(InstanceCullArgs a, trhip::QuadArgs q)
 {
+    // Workgroups past the pass's own (early pass only, when the HZB's footprint-min table is stale): one strip of the table
+    // each (hzb_quad.hip.h).  The meshlet cull behind this pass reads the table; built here it costs no launch of its own and
+    // no cross-stream dependency -- on a rank's share of a sharded scene the side-stream rebuild (fork + join) cost the frame
+    // as much as the table saved it (profiles/r4/experiments.md).
+    if (!LATE && blockIdx.x >= a.numBlocks) {
+        __shared__ float s_t[9][trhip::kQuadStripCols + 1];
+        trhip::hzbQuadStrip(q, blockIdx.x - a.numBlocks, s_t);
+        return;
+    }
     __shared__ uint32_t s_waveG[kBlock / 64], s_waveL[kBlock / 64], s_waveS[kBlock / 64];
     __shared__ unsigned long long s_preG[kBlock / 64], s_preLS[kBlock / 64];
     __shared__ uint32_t s_tile;
@@ -688,6 +698,22 @@ int fillHzb(const trhip::DispatchCtx& ctx, trhip_texture_t* tex, const Vector2U&
     return TRHIP_OK;
 }
 
+// The early fused pass's launch: its own workgroups + (quadOwner, stale table) one workgroup per strip of the HZB's footprint-min table
+std::function<int(hipStream_t)> fusedEarlyLaunch(const InstanceCullArgs& a, trhip_texture_t* quadOwner)
+{
+    return [a, quadOwner](hipStream_t s) {
+        trhip::QuadArgs q;
+        memset(&q, 0, sizeof q);
+        uint32_t strips = 0;
+        if (quadOwner && quadOwner->quadBuiltVersion != quadOwner->version) {            // (submission order: every earlier write of the HZB is counted)
+            q = trhip::quadArgs(quadOwner);
+            strips = q.firstStrip[q.mips];
+            quadOwner->quadBuiltVersion = quadOwner->version;
+        }
+        TRHIP_LAUNCH(instanceFusedKernel<0>, dim3(a.numBlocks + strips), dim3(kBlock), 0, s, a, q);
+        return trhip::launchStatus("instanceFusedKernel"); };
+}
+
 template <int LATE>
 int recordGPUCulling(trhip::DispatchCtx& ctx)
 {
@@ -781,8 +807,11 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
     }
     // The early meshlet cull that follows this pass resolves its HZB lookups through the footprint-min table of
     // this same HZB (k_hzb.hip): bring the table up to date on the side stream while the instance pass runs.
-    if (!LATE && occlusion && a.maxGroups >= trhip::tableMinGroups()) {                 // the rule of recordASMain (k_basepass_as.hip)
-        rc = trhip::hzbQuadEmitBuild(ctx, hzb);
+    static const bool noInlineQuad = getenv("TRHIP_NO_INLINE_QUAD") != nullptr;         // experiments: the side-stream rebuild for small passes too
+    const bool wantTable = !LATE && occlusion && a.maxGroups >= trhip::tableMinGroups(); // the rule of recordASMain (k_basepass_as.hip)
+    const bool inlineQuad = wantTable && fusedPath && !noInlineQuad;                    // small pass: extra workgroups of the fused launch build it
+    if (wantTable) {
+        rc = inlineQuad ? trhip::hzbQuadEnsure(hzb) : trhip::hzbQuadEmitBuild(ctx, hzb);
         if (rc != TRHIP_OK) return rc;
     }
 
@@ -794,10 +823,15 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
         if (rc != TRHIP_OK) return rc;
         a.fusedStatus = (unsigned long long*)mem;
         a.fusedTicket = mem + (size_t)a.numBlocks * kFusedStatusStride * 2;
-        ctx.emit("fused", [a](hipStream_t s) {
-            TRHIP_LAUNCH(instanceFusedKernel<LATE>, dim3(a.numBlocks), dim3(kBlock), 0, s, a);
+        trhip_texture_t* quadOwner = inlineQuad ? hzb : nullptr;
+        if (quadOwner) ctx.cl->use(quadOwner->quad, ctx.cl->ops.size(), true);           // this command (re)writes the table
+        if (LATE) ctx.emit("fused", [a](hipStream_t s) {
+            trhip::QuadArgs q;
+            memset(&q, 0, sizeof q);
+            TRHIP_LAUNCH(instanceFusedKernel<LATE>, dim3(a.numBlocks), dim3(kBlock), 0, s, a, q);
             return trhip::launchStatus("instanceFusedKernel"); });
-        if (!LATE && occlusion) ctx.cl->peephole = { ctx.cl->ops.size() - 1, "gpuculling_early", std::make_shared<EarlyCullNote>(EarlyCullNote{ a, ctx.cl->ops.size() - 1, true }) };
+        else ctx.emit("fused", fusedEarlyLaunch(a, quadOwner));
+        if (!LATE && occlusion) ctx.cl->peephole = { ctx.cl->ops.size() - 1, "gpuculling_early", std::make_shared<EarlyCullNote>(EarlyCullNote{ a, ctx.cl->ops.size() - 1, true, quadOwner }) };
         return TRHIP_OK;
     }
 
@@ -834,10 +868,7 @@ int recordBuildLateArgs(trhip::DispatchCtx& ctx)
             InstanceCullArgs fused = note->a;
             fused.lateArgsOut = a;
             const size_t scanOp = note->scanOp;
-            if (note->fused)
-                ctx.cl->ops[scanOp].fn = [fused](hipStream_t s) {
-                    TRHIP_LAUNCH(instanceFusedKernel<0>, dim3(fused.numBlocks), dim3(kBlock), 0, s, fused);
-                    return trhip::launchStatus("instanceFusedKernel"); };
+            if (note->fused) ctx.cl->ops[scanOp].fn = fusedEarlyLaunch(fused, note->quadOwner);
             else ctx.cl->ops[scanOp].fn = [fused](hipStream_t s) {
                 TRHIP_LAUNCH(instanceScanKernel<0>, dim3(1 + kScanTileGroups), dim3(kScanThreads), 0, s, fused);
                 return trhip::launchStatus("instanceScanKernel"); };

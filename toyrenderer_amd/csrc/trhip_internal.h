@@ -304,10 +304,12 @@ int instanceCacheEnsure(trhip_buffer_t* instances);
 int instanceCacheLaunchBuild(trhip_buffer_t* instances, trhip_buffer_t* meshData, hipStream_t s);
 
 // Record capacity (groups) from which the early meshlet cull resolves its HZB lookups through the footprint-min table
-// (rebuilt per frame on the side stream: a fixed ~20 us) instead of the texels.  TRHIP_TABLE_MIN_GROUPS overrides (tuning).
+// (rebuilt per frame: on the side stream beside a large instance pass, by extra workgroups of a small one's launch) instead of
+// the texels.  2^17: a rank's share of C3 at 8 ranks (390 k groups: 53 instead of 75 us for its early cull); real assets below
+// that keep the texel path.  TRHIP_TABLE_MIN_GROUPS overrides (tuning).
 inline uint32_t tableMinGroups()
 {
-    static const uint32_t v = [] { const char* e = getenv("TRHIP_TABLE_MIN_GROUPS"); return e ? (uint32_t)strtoul(e, nullptr, 0) : (1u << 19); }();
+    static const uint32_t v = [] { const char* e = getenv("TRHIP_TABLE_MIN_GROUPS"); return e ? (uint32_t)strtoul(e, nullptr, 0) : (1u << 17); }();
     return v;
 }
 
