@@ -483,12 +483,12 @@ def self_launch(n: int) -> int:
 
 def kernel_source_sha16() -> str:
     """Identity of the dominant kernel's build: sha256 over the sources of its translation unit and the build flags
-    (toyrenderer_amd/csrc: k_basepass_as.hip, cull_math.hip.h, instance_cache.hip.h, ShaderInterop.h, trhip_internal.h,
+    (toyrenderer_amd/csrc: k_basepass_as.hip, cull_math.hip.h, instance_cache.hip.h, meshlet_exact.hip.h, ShaderInterop.h, trhip_internal.h,
     Makefile).  profiles/r3/traffic.json stores the value of the build its counters were collected on."""
     import hashlib
     h = hashlib.sha256()
     base = os.path.join(ROOT, "toyrenderer_amd", "csrc")
-    for f in ("k_basepass_as.hip", "cull_math.hip.h", "instance_cache.hip.h", "ShaderInterop.h", "trhip_internal.h", "Makefile"):
+    for f in ("k_basepass_as.hip", "cull_math.hip.h", "instance_cache.hip.h", "meshlet_exact.hip.h", "ShaderInterop.h", "trhip_internal.h", "Makefile"):
         with open(os.path.join(base, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]

@@ -629,6 +629,21 @@ def test_three_kernel_instance_pass_on_small_scenes():
     assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
 
 
+def test_texel_kernel_batch_path_on_small_passes():
+    """A pass with at most two records per half-wave of the texel kernel's grid (every late pass, most small early passes of this
+    file: 65 535 records of capacity = 4096 half-waves) skips the kernel's batch machinery: every half-wave evaluates its records
+    exactly from global memory.  TRHIP_NO_SHORT_PASS=1 sends the small cases of this file through the batches as well."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TRHIP_NO_SHORT_PASS="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "all_flag or forced or two_frames or sweep or hostile or cone_test_at or zero_weight or cone_unorm or q1_odd"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
 @pytest.mark.parametrize("flags,table", [(7, False), (7, True), (5, False), (3, True), (6, False)])
 def test_hostile_operands_take_the_exact_arithmetic_path(dev, oracle, flags, table):
     """The cull kernel runs the square roots and divisions of a step on a fast path when every lane of the wave has its

@@ -55,7 +55,7 @@ events)
 emul)
   # rank 0's share at M emulated ranks: no exchange / exchange with a 1-rank RCCL group / loop-back collective (real unpack volume)
   M=${1:-8}; shift || true
-  use base
+  use ${EMUL_LIB:-base}
   for mode in none one loop; do
     case $mode in none) E="TR_NO_GATHER=1";; one) E="";; loop) E="TR_EMULATE_LOOPBACK=1";; esac
     env $E python3 $R/bench.py --emulate-ranks $M --steps 100 --warmup 10 --no-cpu-baseline --no-profile "$@" 2>$OUT/emul_$mode.err | python3 -c "

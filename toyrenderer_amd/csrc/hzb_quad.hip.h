@@ -1,7 +1,8 @@
 // hzb_quad.hip.h -- the footprint-min table of an HZB (trhip_texture_t::quad): layout, arguments, and the strip routine that
-// builds it.  Its own header because TWO launches run the routine: hzbQuadBuildKernel (k_hzb.hip; large passes: on the side
-// stream, beside the instance pass) and instanceFusedKernel<0> (k_gpuculling.hip; small passes: extra workgroups of the
-// instance pass's own launch -- one launch and no cross-stream dependency on a rank's short frame).
+// builds it.  Its own header because several launches run the routine: hzbQuadBuildKernel (k_hzb.hip: the stand-alone build),
+// and, as extra workgroups of the early instance pass's own launches -- no launch of its own, no cross-stream dependency in
+// front of the meshlet cull -- instanceFusedKernel<0> (small passes) and instanceScanKernel<0> (large passes: the scan is
+// seventeen workgroups of dependent round trips, the chip is idle beside it) in k_gpuculling.hip.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -42,10 +43,12 @@ struct QuadArgs
 constexpr uint32_t kQuadStripBlocks = 32;
 constexpr uint32_t kQuadStripCols = kQuadStripBlocks * 8;          // 256 entries per entry row
 
-// builds strip `strip_` (0 .. firstStrip[mips] - 1) of the table; 256 threads, s_t: 9 x 257 floats of LDS
-__device__ __forceinline__ void hzbQuadStrip(const QuadArgs& a, uint32_t strip_, float (*s_t)[kQuadStripCols + 1])
+// Builds strip `strip_` (0 .. firstStrip[mips] - 1) of the table with 256 threads (tid = 0 .. 255), s_t: 9 x 257 floats of LDS.
+// `valid` = false: no strip, the threads only take part in the barrier (every thread of the workgroup calls this once:
+// workgroups of 256 x n threads build n strips side by side).
+__device__ __forceinline__ void hzbQuadStrip(const QuadArgs& a, uint32_t strip_, float (*s_t)[kQuadStripCols + 1], uint32_t tid = threadIdx.x, bool valid = true)
 {
-    const uint32_t tid = threadIdx.x;
+    if (!valid) { __syncthreads(); return; }
     uint32_t k = 0;
     for (uint32_t m = 1; m < a.mips; ++m) k += strip_ >= a.firstStrip[m] ? 1u : 0u;
     const uint32_t mw = (a.width >> k) ? (a.width >> k) : 1u, mh = (a.height >> k) ? (a.height >> k) : 1u;

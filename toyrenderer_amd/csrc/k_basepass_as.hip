@@ -51,6 +51,7 @@ __device__ unsigned long long g_stampSums[8];
 
 #include "cull_math.hip.h"
 #include "instance_cache.hip.h"
+#include "meshlet_exact.hip.h"
 #include "trhip_internal.h"
 
 using namespace interop;
@@ -95,6 +96,10 @@ static_assert(kCullSteps % kRingSlots == 0 && kCullBatch <= 64, "a batch is a wh
 #endif
 constexpr uint32_t kCullWaves = TR_CULL_WAVES;   // meshlet cull: waves per workgroup (= per window of 64 * kCullWaves... records)
 constexpr uint32_t kCullBlock = 64 * kCullWaves;
+#ifndef TR_SHORT_PASS_ROUNDS
+#define TR_SHORT_PASS_ROUNDS 2
+#endif
+constexpr uint32_t kShortPassRounds = TR_SHORT_PASS_ROUNDS;   // texel kernel: passes of at most this many records per half-wave of the grid skip the batch machinery
 constexpr uint32_t kSlotBytes = 1280;            // a ring slot: 64 spheres + 64 cone words (issueMeshletLoads)
 // Deferred mode (meshletCullKernel): the meshlets whose fast evaluation is not certain wait in the wave's list in LDS (kDefStage
 // entries) for their exact re-evaluation: a pass over the whole list at the first batch boundary that finds kDefPassAt entries
@@ -136,59 +141,6 @@ __device__ __forceinline__ cm::M33P adjugateOf(const RecordInfo& ri)
     return { { ri.adjxy[0], ri.adjxy[1] }, { ri.adjxy[2], ri.adjxy[3] }, { ri.adjxy[4], ri.adjxy[5] }, ri.adjz[0], ri.adjz[1], ri.adjz[2] };
 }
 
-// The MESHLET CULL STREAM: per meshlet the cull reads the bounding sphere (16 B) and the cone word (4 B) of the 32-byte
-// MeshletData record (basepass.hlsl:65, :92) -- the other 12 bytes are the mesh shader's.  The kernel's pace is set by the
-// L1 misses a CU can keep in flight (its 256 lines pending most of the time: TCP_PENDING_STALL 65 %), i.e. by the NUMBER OF
-// LINES it asks for: a derived copy of just those 20 bytes, spheres and cone words as two dense arrays, is 10 lines per
-// 64-meshlet step instead of 16.  Back-end private, like the instance cull cache: built on the device from the bound meshlet
-// buffer, rebuilt when that buffer's version moves (meshlets are static per mesh: in practice once per upload), 20 bytes
-// per meshlet of extra memory (C4: 20 GB next to the 32 GB of MeshletData).
-struct MeshletCullStream
-{
-    const float4* sphere;                         // [numMeshlets]
-    const uint32_t* cone;                         // [numMeshlets]
-};
-
-struct MeshletCullArgs
-{
-    BasePassConstants k;
-    const MeshletData* meshlets;
-    MeshletCullStream stream;                     // what the cull reads of them: spheres and cone words as dense arrays (below)
-    const MeshletAmplificationData* records;
-    cm::Hzb hzb;
-    cm::HzbQuad quad;                             // footprint-min table of hzb (k_hzb.hip)
-    const uint32_t* dispatchArgs;                 // {X,1,1[,validRecords]} read on the device
-    uint32_t argsWords;
-    uint32_t recordCapacity;
-    uint64_t numMeshlets;                         // size of the meshlet buffer (bounds check)
-    uint32_t* visMask;
-    uint32_t* visibleList; uint32_t listCapacity;
-    uint32_t* drawArgs;
-    // scratch
-    uint32_t* batchSum;                           // per batch of 64 groups: visible meshlets
-    uint32_t* superSum;                           // per 256 batches: visible meshlets -> exclusive prefix after the super scan
-    uint32_t maxBatches;
-    // optional processing order written by the instance pass into the record buffer's sidecar
-    // (k_gpuculling.hip): {valid, count} header + a permutation of [0, count) sorted by screen tile
-    const uint32_t* permHeader;
-    const uint4* perm;                            // {record index, instance, first meshlet, count} in processing order
-    InstanceCullCache cache;                      // world matrix, max scale, LOD table per instance (instance_cache.hip.h)
-    uint32_t numInstances;
-    // The group count the list build works on: written by the cull kernel (G of groupCount()), read by count / scan / expand /
-    // compact INSTEAD of the dispatch arguments.  The list build of a large pass runs on the side stream, past the end of the
-    // frame's main chain; the next frame starts by clearing the dispatch arguments (BasePassRenderers.cpp:322-332), and with
-    // the arguments as the list build's input that clear -- the head of the next frame's chain -- had to wait for it (a
-    // cross-stream join, exposed: ~20 us per frame on C3, profiles/r4/experiments.md section 2).
-    uint32_t* listGroups;
-    cm::ProjBands bands;                          // filtered projection: preconditions and bands (cm::projBands, computed on the host)
-};
-
-__device__ __forceinline__ uint32_t groupCount(const MeshletCullArgs& a)
-{
-    uint32_t G = a.dispatchArgs[0];
-    if (a.argsWords > 3 && a.dispatchArgs[3] < G) G = a.dispatchArgs[3];   // Q2: only the defined prefix
-    return G < a.recordCapacity ? G : a.recordCapacity;
-}
 __device__ __forceinline__ uint32_t listGroupCount(const MeshletCullArgs& a)      // the list build's view of it (MeshletCullArgs::listGroups)
 {
     return a.listGroups ? a.listGroups[0] : groupCount(a);
@@ -267,45 +219,6 @@ __device__ __forceinline__ void issueMeshletLoads(char* slotLds /* wave-uniform 
 #define TR_STAMP(i) do {} while (0)
 #endif
 
-// Exact visibility of meshlet `mi` of instance `cid`, from global memory alone (the path of the texel kernel: every test with the
-// compiler's correctly rounded sequences, basepass.hlsl:65-108).  What the deferred mode's re-evaluations run.
-template <bool FRUSTUM, bool OCCLUSION, bool CONE>
-__device__ __forceinline__ bool exactMeshletAt(const MeshletCullArgs& a, const cm::M43P& VP, const cm::M33P& VR, uint32_t cid, uint64_t mi)
-{
-    const float4* wr = a.cache.world + 4ull * cid;
-    const float4* p = reinterpret_cast<const float4*>(a.meshlets + mi);
-    const float4 q0 = wr[0], q1 = wr[1], q2 = wr[2], q3 = wr[3];
-    const float4 sphere = p[0];
-    const uint32_t cone = __float_as_uint(p[1].x);
-    const cm::F3 r0 = { q0.x, q0.y, q0.z }, r1 = { q0.w, q1.x, q1.y }, r2 = { q1.z, q1.w, q2.x };
-    const cm::M43P W = cm::packM43(cm::M43{ r0, r1, r2, { q2.y, q2.z, q2.w } });
-    const cm::M33P adj = cm::rot(cm::packM43(cm::M43{ cm::cross3(r1, r2), cm::cross3(r2, r0), cm::cross3(r0, r1), { 0.f, 0.f, 0.f } }));
-    const cm::F3 cv = cm::toViewP(cm::mulPointP({ sphere.x, sphere.y, sphere.z }, W), VP);
-    const float rad = sphere.w * q3.x;
-    bool vis = true;
-    if (FRUSTUM) vis &= cm::frustumVisible(cv, rad, a.k.m_Frustum.x, a.k.m_Frustum.y, a.k.m_Frustum.z, a.k.m_Frustum.w);
-    if (OCCLUSION) vis &= cm::occlusionVisible(cv, rad, a.k.m_NearPlane, a.k.m_P00, a.k.m_P11, a.hzb);
-    float unused;
-    if (CONE) vis &= !cm::coneBackfacingP(cone, cv, rad, adj, VR, 1.0f, 1.0f, &unused);
-    return vis;
-}
-// ... of lane m of record g (basepass.hlsl:52-63 first)
-template <bool FRUSTUM, bool OCCLUSION, bool CONE>
-__device__ __forceinline__ bool exactMeshletVisible(const MeshletCullArgs& a, const cm::M43P& VP, const cm::M33P& VR, uint32_t g, uint32_t m)
-{
-    const MeshletAmplificationData rec = a.records[g];
-    const uint32_t cid = rec.m_InstanceConstIdx < a.numInstances ? rec.m_InstanceConstIdx : 0u;
-    const uint32_t lodIdx = rec.m_MeshLOD < kMaxNumMeshLODs ? rec.m_MeshLOD : kMaxNumMeshLODs - 1u;
-    const uint2 li = a.cache.lod(cid, lodIdx);
-    const uint32_t off = rec.m_MeshletGroupOffset;
-    uint32_t cnt = li.x > off ? li.x - off : 0u;
-    const uint64_t base = (uint64_t)li.y + off;
-    cnt = cnt < 32u ? cnt : 32u;
-    if (base + cnt > a.numMeshlets) cnt = 0;
-    if (m >= cnt) return false;
-    return exactMeshletAt<FRUSTUM, OCCLUSION, CONE>(a, VP, VR, cid, base + m);
-}
-
 // TABLE: resolve the HZB lookup through the footprint-min table (one 2-byte load; the early pass, where the
 // table is rebuilt once per frame behind the instance pass) or through the texels themselves (two texel-pair
 // loads; the late pass, which is small and follows an HZB rebuild).  Same results either way.
@@ -355,6 +268,20 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
     const cm::M43P VP = cm::packM43(V);
     const cm::M33P VR = cm::rot(VP);
     const float coneSlack = cm::coneSlackFactor(V);
+    // SHORT PASSES (texel kernel: late passes, small early passes): the batch machinery below gives a wave 64 records to walk
+    // in 32 serial steps -- right for a million records, but a late pass of C3 has 2 544 (0.15 % of the frame's meshlets):
+    // ten workgroups walked them for 8-10 us (25 us beside the early list's expansion) while the rest of the grid looked on.
+    // When the grid has a half-wave for every record (twice over), every half-wave evaluates its record's 32 meshlets exactly
+    // from global memory (exactMeshletVisible: the sequences the step loop's fallbacks run, same results) -- one chain of
+    // dependent loads for the whole pass instead of 32 in a row.
+    if (!TABLE && G <= gridDim.x * (2u * kCullWaves) * a.shortPassRounds) {
+        for (uint32_t g = (blockIdx.x * kCullWaves + wave) * 2u + half; g < G; g += gridDim.x * kCullWaves * 2u) {
+            const bool vis = exactMeshletVisible<FRUSTUM, OCCLUSION, CONE>(a, VP, VR, g, sub);
+            const unsigned long long b = __ballot(vis);
+            if (sub == 0) a.visMask[g] = (uint32_t)(half ? b >> 32 : b);
+        }
+        return;
+    }
     RecordInfo* s_rec = s_recAll[wave];
     uint32_t* s_gIdx = s_gIdxAll[wave];
 
@@ -1682,6 +1609,8 @@ int recordASMain(trhip::DispatchCtx& ctx)
     a.listGroups = (uint32_t*)visMask->sidecar;
     ctx.cl->use(a.listGroups, ctx.cl->ops.size(), true);
     if (useTable) a.bands = cm::projBands(k->m_P00, k->m_P11, hzb->width, hzb->height);
+    static const bool noShortPass = getenv("TRHIP_NO_SHORT_PASS") != nullptr;          // tests: the texel kernel's batch path on small passes too
+    a.shortPassRounds = noShortPass ? 0u : kShortPassRounds;
     const uint32_t flags = k->m_CullingFlags & 7u;
     trhip_texture_t* quadOwner = useTable ? hzb : nullptr;
     const bool table = useTable;

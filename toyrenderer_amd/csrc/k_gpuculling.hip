@@ -302,10 +302,21 @@ __global__ __launch_bounds__(kBigThreads) void instanceClassifyKernel(InstanceCu
     }
 }
 
+constexpr uint32_t kScanStripsPerGroup = kScanThreads / 256u;             // table strips a workgroup past the scan's own builds
 template <int LATE>
-__global__ __launch_bounds__(kScanThreads) void instanceScanKernel(InstanceCullArgs a)
+__global__ __launch_bounds__(kScanThreads) void instanceScanKernel(InstanceCullArgs a, trhip::QuadArgs q)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // Workgroups past the scan's own (early pass only, when the HZB's footprint-min table is stale): four strips of the table each
+    // (hzb_quad.hip.h).  The meshlet cull behind this pass reads the table.  The scan is seventeen workgroups of dependent round
+    // trips; the table (11 MB read, 11 MB written) is built on the CUs idle beside it instead of on the side stream beside
+    // classify -- one fork and one join less in front of the meshlet cull (7 us of gap on C3, profiles/r4/experiments.md).
+    if (!LATE && blockIdx.x > kScanTileGroups) {
+        __shared__ float s_t[kScanStripsPerGroup][9][trhip::kQuadStripCols + 1];
+        const uint32_t strip = (blockIdx.x - kScanTileGroups - 1u) * kScanStripsPerGroup + (tid >> 8);
+        trhip::hzbQuadStrip(q, strip, s_t[tid >> 8], tid & 255u, strip < q.firstStrip[q.mips]);
+        return;
+    }
     if (blockIdx.x != 0) {
         // ---- tile columns: H[b][t] <- groups of tile t in workgroups < b; T[t] <- all of them -------------------------
         // The kernel is a chain of dependent round trips (list length -> rows -> sums -> rows again) around very little
@@ -714,6 +725,22 @@ std::function<int(hipStream_t)> fusedEarlyLaunch(const InstanceCullArgs& a, trhi
         return trhip::launchStatus("instanceFusedKernel"); };
 }
 
+// The early three-kernel pass's scan launch: its own workgroups + (quadOwner, stale table) one workgroup per four table strips
+std::function<int(hipStream_t)> scanEarlyLaunch(const InstanceCullArgs& a, trhip_texture_t* quadOwner)
+{
+    return [a, quadOwner](hipStream_t s) {
+        trhip::QuadArgs q;
+        memset(&q, 0, sizeof q);
+        uint32_t extra = 0;
+        if (quadOwner && quadOwner->quadBuiltVersion != quadOwner->version) {            // (submission order: every earlier write of the HZB is counted)
+            q = trhip::quadArgs(quadOwner);
+            extra = (q.firstStrip[q.mips] + kScanStripsPerGroup - 1u) / kScanStripsPerGroup;
+            quadOwner->quadBuiltVersion = quadOwner->version;
+        }
+        TRHIP_LAUNCH(instanceScanKernel<0>, dim3(1 + kScanTileGroups + extra), dim3(kScanThreads), 0, s, a, q);
+        return trhip::launchStatus("instanceScanKernel"); };
+}
+
 template <int LATE>
 int recordGPUCulling(trhip::DispatchCtx& ctx)
 {
@@ -809,7 +836,7 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
     // this same HZB (k_hzb.hip): bring the table up to date on the side stream while the instance pass runs.
     static const bool noInlineQuad = getenv("TRHIP_NO_INLINE_QUAD") != nullptr;         // experiments: the side-stream rebuild for small passes too
     const bool wantTable = !LATE && occlusion && a.maxGroups >= trhip::tableMinGroups(); // the rule of recordASMain (k_basepass_as.hip)
-    const bool inlineQuad = wantTable && fusedPath && !noInlineQuad;                    // small pass: extra workgroups of the fused launch build it
+    const bool inlineQuad = wantTable && !noInlineQuad;                                 // extra workgroups of the fused launch (small pass) / of the scan launch (large pass) build it
     if (wantTable) {
         rc = inlineQuad ? trhip::hzbQuadEnsure(hzb) : trhip::hzbQuadEmitBuild(ctx, hzb);
         if (rc != TRHIP_OK) return rc;
@@ -838,14 +865,19 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
     ctx.emit("classify", [a](hipStream_t s) {
         TRHIP_LAUNCH(instanceClassifyKernel<LATE>, dim3(a.numBlocks), dim3(kBigThreads), 0, s, a);
         return trhip::launchStatus("instanceClassifyKernel"); });
-    ctx.emit("scan", [a](hipStream_t s) {
-        TRHIP_LAUNCH(instanceScanKernel<LATE>, dim3(1 + kScanTileGroups), dim3(kScanThreads), 0, s, a);
+    trhip_texture_t* quadOwner = inlineQuad ? hzb : nullptr;
+    if (quadOwner) ctx.cl->use(quadOwner->quad, ctx.cl->ops.size(), true);               // the scan command (re)writes the table
+    if (LATE) ctx.emit("scan", [a](hipStream_t s) {
+        trhip::QuadArgs q;
+        memset(&q, 0, sizeof q);
+        TRHIP_LAUNCH(instanceScanKernel<LATE>, dim3(1 + kScanTileGroups), dim3(kScanThreads), 0, s, a, q);
         return trhip::launchStatus("instanceScanKernel"); });
+    else ctx.emit("scan", scanEarlyLaunch(a, quadOwner));
     const size_t scanOp = ctx.cl->ops.size() - 1;
     ctx.emit("emit", [a](hipStream_t s) {
         TRHIP_LAUNCH(instanceEmitKernel<LATE>, dim3(a.numBlocks), dim3(kBigThreads), 0, s, a);
         return trhip::launchStatus("instanceEmitKernel"); });
-    if (!LATE && occlusion) ctx.cl->peephole = { ctx.cl->ops.size() - 1, "gpuculling_early", std::make_shared<EarlyCullNote>(EarlyCullNote{ a, scanOp, false }) };
+    if (!LATE && occlusion) ctx.cl->peephole = { ctx.cl->ops.size() - 1, "gpuculling_early", std::make_shared<EarlyCullNote>(EarlyCullNote{ a, scanOp, false, quadOwner }) };
     return TRHIP_OK;
 }
 
@@ -869,9 +901,7 @@ int recordBuildLateArgs(trhip::DispatchCtx& ctx)
             fused.lateArgsOut = a;
             const size_t scanOp = note->scanOp;
             if (note->fused) ctx.cl->ops[scanOp].fn = fusedEarlyLaunch(fused, note->quadOwner);
-            else ctx.cl->ops[scanOp].fn = [fused](hipStream_t s) {
-                TRHIP_LAUNCH(instanceScanKernel<0>, dim3(1 + kScanTileGroups), dim3(kScanThreads), 0, s, fused);
-                return trhip::launchStatus("instanceScanKernel"); };
+            else ctx.cl->ops[scanOp].fn = scanEarlyLaunch(fused, note->quadOwner);
             // this dispatch's accesses (count read, arguments written) now happen in the scan command
             for (size_t i = ctx.cl->useMarks.size(); i-- > 0 && ctx.cl->useMarks[i].op >= ctx.cl->ops.size();) ctx.cl->useMarks[i].op = scanOp;
             ctx.cl->peephole = trhip_cmdlist_t::Peephole();
