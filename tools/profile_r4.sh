@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round-4 evidence run on the GPU box (from the repo root, through gpurun; needs the variant builds count, stamps, r3stamps,
 # noband under toyrenderer_amd/lib/exp -- tools/variants.sh, see tools/README.md).  One run, after the last change to the
-# hashed kernel sources; tools/collect_r4.py turns gpurun_out/r4_final/ into profiles/r4/final_*.
+# hashed kernel sources; tools/collect_r4.py (run once on the box, for traffic.json, and once here) turns gpurun_out/r4_final/
+# into profiles/r4/final_*.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 LIB=$R/toyrenderer_amd/lib
 OUT=$R/gpurun_out/r4_final
@@ -9,9 +10,6 @@ rm -rf $OUT; mkdir -p $OUT
 use() { if [ "$1" = base ]; then unset TRHIP_LIB; export LD_LIBRARY_PATH=$LIB; else export TRHIP_LIB=$LIB/exp/$1/libtrhip.so; export LD_LIBRARY_PATH=$LIB/exp/$1; fi; }
 use base
 cd /tmp && export TMPDIR=/tmp
-echo "== bench lines"; date +%T
-python3 $R/bench.py > $OUT/final_bench.json 2> $OUT/final_bench.log
-python3 $R/bench.py --steps 20 --warmup 5 > $OUT/final_bench_20steps.json 2> $OUT/final_bench_20steps.log
 echo "== kernel trace"; date +%T
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-profile > $OUT/final_bench_under_rocprof.json 2> $OUT/trace.log   # (--no-profile: the timed frames only -- the last frame of the trace is a steady-state one)
 f=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
@@ -29,6 +27,11 @@ for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAI
   timeout -k 5 150 rocprofv3 --pmc $G --output-format csv -d $OUT/pmc/g$i -- python3 $R/bench.py --steps 3 --warmup 2 --prime-steps 8 --no-cpu-baseline --no-profile > /dev/null 2> $OUT/pmc_g$i.log || tail -3 $OUT/pmc_g$i.log
   i=$((i+1))
 done
+echo "== traffic.json from this box's trace + PMC passes, then the bench lines (they report traffic / trace only with it in place)"; date +%T
+python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-animated-leg > $OUT/final_bench.json 2> /dev/null     # (placeholder: algorithmic bytes per launch for collect_r4.py)
+(cd $R && python3 tools/collect_r4.py > $OUT/collect_on_box.txt 2>&1) || tail -5 $OUT/collect_on_box.txt
+python3 $R/bench.py > $OUT/final_bench.json 2> $OUT/final_bench.log
+python3 $R/bench.py --steps 20 --warmup 5 > $OUT/final_bench_20steps.json 2> $OUT/final_bench_20steps.log
 echo "== stamps, counts, events, sync cost"; date +%T
 for v in r3stamps stamps; do use $v; echo "== $v"; TRHIP_AS_BLOCKS_PER_CU=5 python3 $R/tools/stamps.py 2>/dev/null | tail -9; done > $OUT/stamps.txt
 use count; python3 $R/tools/count_slow.py 2>/dev/null | tail -2 > $OUT/deferred_counts.txt

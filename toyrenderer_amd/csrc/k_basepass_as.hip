@@ -32,7 +32,8 @@
 //     decides goes on the wave's list in LDS and is re-evaluated exactly, 32-64 lanes at a time, at batch boundaries;
 //   * texel kernel (small passes, late passes, the deferred mode's last resort): cm::stepQuotients -- the exact IEEE square
 //     roots and divisions without the v_div_scale / v_div_fmas / v_div_fixup glue whenever the whole wave's operands allow
-//     it -- and two texel-pair loads per lookup;
+//     it -- and two texel-pair loads per lookup.  A SHORT pass (at most two records per half-wave of the grid: every late
+//     pass of C3) skips the batches: each half-wave evaluates its records exactly from global memory (exactMeshletVisible);
 //   * the loop issues no stores: the 32 masks of a batch (WaveActiveCountBits / WavePrefixCountBits :116-120 = the two
 //     halves of the ballot) are staged in LDS and leave in one store per wave and batch.
 #include <algorithm>
@@ -268,12 +269,12 @@ __global__ __launch_bounds__(kCullBlock, TR_CULL_WAVES_PER_EU) void meshletCullK
     const cm::M43P VP = cm::packM43(V);
     const cm::M33P VR = cm::rot(VP);
     const float coneSlack = cm::coneSlackFactor(V);
-    // SHORT PASSES (texel kernel: late passes, small early passes): the batch machinery below gives a wave 64 records to walk
-    // in 32 serial steps -- right for a million records, but a late pass of C3 has 2 544 (0.15 % of the frame's meshlets):
-    // ten workgroups walked them for 8-10 us (25 us beside the early list's expansion) while the rest of the grid looked on.
-    // When the grid has a half-wave for every record (twice over), every half-wave evaluates its record's 32 meshlets exactly
-    // from global memory (exactMeshletVisible: the sequences the step loop's fallbacks run, same results) -- one chain of
-    // dependent loads for the whole pass instead of 32 in a row.
+    // SHORT PASSES (texel kernel: late passes, small early passes): the batch machinery below gives a wave kCullBatch records to
+    // walk in kCullSteps serial steps -- right for a million records, but the late pass of C3 has 2 544 (0.15 % of the frame's
+    // meshlets): twenty workgroups walked them for 8-10 us while the rest of the grid looked on.  When the grid has a half-wave
+    // for every record (kShortPassRounds times over), every half-wave evaluates its record's 32 meshlets exactly from global
+    // memory (exactMeshletVisible: the sequences the step loop's fallbacks run, same results) -- one chain of dependent loads for
+    // the whole pass instead of sixteen in a row.
     if (!TABLE && G <= gridDim.x * (2u * kCullWaves) * a.shortPassRounds) {
         for (uint32_t g = (blockIdx.x * kCullWaves + wave) * 2u + half; g < G; g += gridDim.x * kCullWaves * 2u) {
             const bool vis = exactMeshletVisible<FRUSTUM, OCCLUSION, CONE>(a, VP, VR, g, sub);
