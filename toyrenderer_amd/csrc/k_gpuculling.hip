@@ -833,8 +833,8 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
         a.permCapacity = a.maxGroups;
     }
     // The early meshlet cull that follows this pass resolves its HZB lookups through the footprint-min table of
-    // this same HZB (k_hzb.hip): bring the table up to date on the side stream while the instance pass runs.
-    static const bool noInlineQuad = getenv("TRHIP_NO_INLINE_QUAD") != nullptr;         // experiments: the side-stream rebuild for small passes too
+    // this same HZB (hzb_quad.hip.h): bring the table up to date with extra workgroups of this pass's own scan / fused launch.
+    static const bool noInlineQuad = getenv("TRHIP_NO_INLINE_QUAD") != nullptr;         // experiments: its own launch on the side stream, beside the instance pass
     const bool wantTable = !LATE && occlusion && a.maxGroups >= trhip::tableMinGroups(); // the rule of recordASMain (k_basepass_as.hip)
     const bool inlineQuad = wantTable && !noInlineQuad;                                 // extra workgroups of the fused launch (small pass) / of the scan launch (large pass) build it
     if (wantTable) {
