@@ -617,14 +617,15 @@ def test_instance_pass_continues_from_nonzero_counters(dev, oracle, flags, mid_c
 
 def test_three_kernel_instance_pass_on_small_scenes():
     """Small passes run classify + scan + emit as ONE launch (instanceFusedKernel); the three-kernel path then only sees
-    the full-size configs.  TRHIP_NO_FUSED_INSTANCE=1 sends the small cases of this file through it as well."""
+    the full-size configs.  TRHIP_NO_FUSED_INSTANCE=1 sends the small cases of this file through it as well -- incl. the
+    table-kernel cases on small and non-square HZBs: the scan launch's extra workgroups build their footprint tables."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, TRHIP_NO_FUSED_INSTANCE="1")
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
-                        "-k", "all_flag or late_dispatch or group_cap or two_frames or sweep or empty or forced or continues_from"],
+                        "-k", "all_flag or late_dispatch or group_cap or two_frames or sweep or empty or forced or continues_from or table_kernel_on_small"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
 
