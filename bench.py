@@ -379,7 +379,7 @@ def main():
                         valu_active=valu_active,
                         note="frac = the reference's bytes (32 B MeshletData per meshlet, SURVEY 8d) / the kernel's time / 8 TB/s, as the contract "
                              "asks; the kernel streams a derived 20-byte copy (traffic, frac_by_traffic = the HBM fraction of the bytes that "
-                             "moved) and is paced by the stream's L1 misses in flight (valu_active = SQ_ACTIVE_INST_VALU / SIMD cycles, PMC; "
+                             "moved) and is paced by its L1 misses in flight, stream and HZB-table lookups together (valu_active = SQ_ACTIVE_INST_VALU / SIMD cycles, PMC; "
                              "profiles/r4/experiments.md section 5).  avg_launch_ms: HIP events in steady state, only this kernel bracketed; "
                              "avg_launch_ms_trace: the committed rocprofv3 kernel trace",
                         frame_frac=round(frame_frac, 4) if frame_frac is not None else None, frame_algorithmic_bytes=int(frame_alg),
