@@ -1,8 +1,9 @@
 // hzb_quad.hip.h -- the footprint-min table of an HZB (trhip_texture_t::quad): layout, arguments, and the strip routine that
 // builds it.  Its own header because several launches run the routine: hzbQuadBuildKernel (k_hzb.hip: the stand-alone build),
 // and, as extra workgroups of the early instance pass's own launches -- no launch of its own, no cross-stream dependency in
-// front of the meshlet cull -- instanceFusedKernel<0> (small passes) and instanceScanKernel<0> (large passes: the scan is
-// seventeen workgroups of dependent round trips, the chip is idle beside it) in k_gpuculling.hip.
+// front of the meshlet cull -- instanceFusedKernel<0> (small passes) and instanceScanKernel<0> + instanceEmitKernel<0> (large
+// passes: half of the strips beside the scan's seventeen workgroups of dependent round trips, half behind the emit's own
+// workgroups) in k_gpuculling.hip.
 #pragma once
 
 #include <hip/hip_runtime.h>

@@ -72,7 +72,8 @@ struct InstanceCullArgs
 };
 
 // What an early recordGPUCulling leaves for a recordBuildLateArgs that follows it immediately (trhip_cmdlist_t::peephole).
-struct EarlyCullNote { InstanceCullArgs a; size_t scanOp; bool fused; trhip_texture_t* quadOwner = nullptr; };
+struct QuadShare { bool stale = false; };   // large passes: the scan launch decides whether the table is rebuilt, the emit launch builds its share
+struct EarlyCullNote { InstanceCullArgs a; size_t scanOp; bool fused; trhip_texture_t* quadOwner = nullptr; std::shared_ptr<QuadShare> share; };
 
 __global__ __launch_bounds__(256) void instanceCacheKernel(const BasePassInstanceConstants* instances, uint32_t n,
                                                            const MeshData* meshData, uint32_t numMeshes, InstanceCullCache c)
@@ -304,17 +305,19 @@ __global__ __launch_bounds__(kBigThreads) void instanceClassifyKernel(InstanceCu
 
 constexpr uint32_t kScanStripsPerGroup = kScanThreads / 256u;             // table strips a workgroup past the scan's own builds
 template <int LATE>
-__global__ __launch_bounds__(kScanThreads) void instanceScanKernel(InstanceCullArgs a, trhip::QuadArgs q)
+__global__ __launch_bounds__(kScanThreads) void instanceScanKernel(InstanceCullArgs a, trhip::QuadArgs q, uint32_t stripEnd)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     // Workgroups past the scan's own (early pass only, when the HZB's footprint-min table is stale): four strips of the table each
     // (hzb_quad.hip.h).  The meshlet cull behind this pass reads the table.  The scan is seventeen workgroups of dependent round
-    // trips; the table (11 MB read, 11 MB written) is built on the CUs idle beside it instead of on the side stream beside
-    // classify -- one fork and one join less in front of the meshlet cull (7 us of gap on C3, profiles/r4/experiments.md).
+    // trips: the first strips [0, stripEnd) of the table (11 MB read, 11 MB written in all) are built on the CUs idle beside it,
+    // the rest by extra workgroups of the emit launch -- no launch of its own, no fork and join in front of the meshlet cull
+    // (side stream beside classify: 20 + 9 + 16 us and a 7-us join; all strips here: 17 + 17 + 16; all in emit: 18 + 9 + 22;
+    // half and half: profiles/r4/experiments.md section 7).
     if (!LATE && blockIdx.x > kScanTileGroups) {
         __shared__ float s_t[kScanStripsPerGroup][9][trhip::kQuadStripCols + 1];
         const uint32_t strip = (blockIdx.x - kScanTileGroups - 1u) * kScanStripsPerGroup + (tid >> 8);
-        trhip::hzbQuadStrip(q, strip, s_t[tid >> 8], tid & 255u, strip < q.firstStrip[q.mips]);
+        trhip::hzbQuadStrip(q, strip, s_t[tid >> 8], tid & 255u, strip < stripEnd);
         return;
     }
     if (blockIdx.x != 0) {
@@ -446,9 +449,17 @@ __global__ __launch_bounds__(kScanThreads) void instanceScanKernel(InstanceCullA
     }
 }
 
+constexpr uint32_t kEmitStripsPerGroup = kBigThreads / 256u;
 template <int LATE>
-__global__ __launch_bounds__(kBigThreads) void instanceEmitKernel(InstanceCullArgs a)
+__global__ __launch_bounds__(kBigThreads) void instanceEmitKernel(InstanceCullArgs a, trhip::QuadArgs q, uint32_t stripBegin)
 {
+    // Workgroups past the pass's own: the strips [stripBegin, all) of the HZB's footprint-min table the scan launch left (see there)
+    if (!LATE && blockIdx.x >= a.numBlocks) {
+        __shared__ float s_t[kEmitStripsPerGroup][9][trhip::kQuadStripCols + 1];
+        const uint32_t strip = stripBegin + (blockIdx.x - a.numBlocks) * kEmitStripsPerGroup + (threadIdx.x >> 8);
+        trhip::hzbQuadStrip(q, strip, s_t[threadIdx.x >> 8], threadIdx.x & 255u, strip < q.firstStrip[q.mips]);
+        return;
+    }
     __shared__ uint32_t s_cursor[kNumTiles];
     __shared__ uint32_t s_wave[kBigWaves];
     const uint32_t n = threadCount<LATE>(a);
@@ -725,19 +736,30 @@ std::function<int(hipStream_t)> fusedEarlyLaunch(const InstanceCullArgs& a, trhi
         return trhip::launchStatus("instanceFusedKernel"); };
 }
 
-// The early three-kernel pass's scan launch: its own workgroups + (quadOwner, stale table) one workgroup per four table strips
-std::function<int(hipStream_t)> scanEarlyLaunch(const InstanceCullArgs& a, trhip_texture_t* quadOwner)
+// Share of the table's strips built in the scan launch (the rest in the emit launch): TRHIP_QUAD_SCAN_PERCENT, experiments
+inline uint32_t quadScanStrips(uint32_t all)
 {
-    return [a, quadOwner](hipStream_t s) {
+    static const uint32_t pct = [] { const char* e = getenv("TRHIP_QUAD_SCAN_PERCENT"); const int v = e ? atoi(e) : 50; return (uint32_t)(v < 0 ? 0 : v > 100 ? 100 : v); }();
+    return (uint32_t)((uint64_t)all * pct / 100u);
+}
+
+// The early three-kernel pass's scan launch: its own workgroups + (quadOwner, stale table) one workgroup per four table strips of
+// its share; `share` tells the emit launch of the same pass whether the table is being rebuilt
+std::function<int(hipStream_t)> scanEarlyLaunch(const InstanceCullArgs& a, trhip_texture_t* quadOwner, std::shared_ptr<QuadShare> share)
+{
+    return [a, quadOwner, share](hipStream_t s) {
         trhip::QuadArgs q;
         memset(&q, 0, sizeof q);
-        uint32_t extra = 0;
+        uint32_t extra = 0, stripEnd = 0;
+        if (share) share->stale = false;
         if (quadOwner && quadOwner->quadBuiltVersion != quadOwner->version) {            // (submission order: every earlier write of the HZB is counted)
             q = trhip::quadArgs(quadOwner);
-            extra = (q.firstStrip[q.mips] + kScanStripsPerGroup - 1u) / kScanStripsPerGroup;
+            stripEnd = share ? quadScanStrips(q.firstStrip[q.mips]) : q.firstStrip[q.mips];
+            extra = (stripEnd + kScanStripsPerGroup - 1u) / kScanStripsPerGroup;
             quadOwner->quadBuiltVersion = quadOwner->version;
+            if (share) share->stale = true;
         }
-        TRHIP_LAUNCH(instanceScanKernel<0>, dim3(1 + kScanTileGroups + extra), dim3(kScanThreads), 0, s, a, q);
+        TRHIP_LAUNCH(instanceScanKernel<0>, dim3(1 + kScanTileGroups + extra), dim3(kScanThreads), 0, s, a, q, stripEnd);
         return trhip::launchStatus("instanceScanKernel"); };
 }
 
@@ -866,18 +888,28 @@ int recordGPUCulling(trhip::DispatchCtx& ctx)
         TRHIP_LAUNCH(instanceClassifyKernel<LATE>, dim3(a.numBlocks), dim3(kBigThreads), 0, s, a);
         return trhip::launchStatus("instanceClassifyKernel"); });
     trhip_texture_t* quadOwner = inlineQuad ? hzb : nullptr;
-    if (quadOwner) ctx.cl->use(quadOwner->quad, ctx.cl->ops.size(), true);               // the scan command (re)writes the table
+    std::shared_ptr<QuadShare> share = quadOwner ? std::make_shared<QuadShare>() : nullptr;
+    if (quadOwner) ctx.cl->use(quadOwner->quad, ctx.cl->ops.size(), true);               // the scan command (re)writes the table (and the emit command behind it)
     if (LATE) ctx.emit("scan", [a](hipStream_t s) {
         trhip::QuadArgs q;
         memset(&q, 0, sizeof q);
-        TRHIP_LAUNCH(instanceScanKernel<LATE>, dim3(1 + kScanTileGroups), dim3(kScanThreads), 0, s, a, q);
+        TRHIP_LAUNCH(instanceScanKernel<LATE>, dim3(1 + kScanTileGroups), dim3(kScanThreads), 0, s, a, q, 0u);
         return trhip::launchStatus("instanceScanKernel"); });
-    else ctx.emit("scan", scanEarlyLaunch(a, quadOwner));
+    else ctx.emit("scan", scanEarlyLaunch(a, quadOwner, share));
     const size_t scanOp = ctx.cl->ops.size() - 1;
-    ctx.emit("emit", [a](hipStream_t s) {
-        TRHIP_LAUNCH(instanceEmitKernel<LATE>, dim3(a.numBlocks), dim3(kBigThreads), 0, s, a);
+    if (quadOwner) ctx.cl->use(quadOwner->quad, ctx.cl->ops.size(), true);               // the emit command writes the rest of the table
+    ctx.emit("emit", [a, quadOwner, share](hipStream_t s) {
+        trhip::QuadArgs q;
+        memset(&q, 0, sizeof q);
+        uint32_t extra = 0, stripBegin = 0;
+        if (!LATE && quadOwner && share && share->stale) {                                  // the scan launch of this pass rebuilt the first strips
+            q = trhip::quadArgs(quadOwner);
+            stripBegin = quadScanStrips(q.firstStrip[q.mips]);
+            extra = (q.firstStrip[q.mips] - stripBegin + kEmitStripsPerGroup - 1u) / kEmitStripsPerGroup;
+        }
+        TRHIP_LAUNCH(instanceEmitKernel<LATE>, dim3(a.numBlocks + extra), dim3(kBigThreads), 0, s, a, q, stripBegin);
         return trhip::launchStatus("instanceEmitKernel"); });
-    if (!LATE && occlusion) ctx.cl->peephole = { ctx.cl->ops.size() - 1, "gpuculling_early", std::make_shared<EarlyCullNote>(EarlyCullNote{ a, scanOp, false, quadOwner }) };
+    if (!LATE && occlusion) ctx.cl->peephole = { ctx.cl->ops.size() - 1, "gpuculling_early", std::make_shared<EarlyCullNote>(EarlyCullNote{ a, scanOp, false, quadOwner, share }) };
     return TRHIP_OK;
 }
 
@@ -901,7 +933,7 @@ int recordBuildLateArgs(trhip::DispatchCtx& ctx)
             fused.lateArgsOut = a;
             const size_t scanOp = note->scanOp;
             if (note->fused) ctx.cl->ops[scanOp].fn = fusedEarlyLaunch(fused, note->quadOwner);
-            else ctx.cl->ops[scanOp].fn = scanEarlyLaunch(fused, note->quadOwner);
+            else ctx.cl->ops[scanOp].fn = scanEarlyLaunch(fused, note->quadOwner, note->share);
             // this dispatch's accesses (count read, arguments written) now happen in the scan command
             for (size_t i = ctx.cl->useMarks.size(); i-- > 0 && ctx.cl->useMarks[i].op >= ctx.cl->ops.size();) ctx.cl->useMarks[i].op = scanOp;
             ctx.cl->peephole = trhip_cmdlist_t::Peephole();
