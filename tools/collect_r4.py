@@ -16,7 +16,13 @@ for f in ("final_bench.json", "final_bench_20steps.json", "final_bench_under_roc
     else:
         print("missing", f)
 d = collections.defaultdict(lambda: collections.defaultdict(list))
+# gpurun MERGES a run's files into the local gpurun_out/: an earlier collection's CSVs (other file names) are still there.  One
+# file per counter group: the newest.
+newest = {}
 for f in glob.glob(os.path.join(src, "pmc", "g*", "**", "*counter_collection.csv"), recursive=True):
+    g = os.path.relpath(f, os.path.join(src, "pmc")).split(os.sep)[0]
+    if g not in newest or os.path.getmtime(f) > os.path.getmtime(newest[g]): newest[g] = f
+for f in newest.values():
     for r in csv.DictReader(open(f)):
         if "meshletCullKernel" in r["Kernel_Name"]:
             d[r["Kernel_Name"].replace("(anonymous namespace)::", "")[:70]][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
