@@ -305,20 +305,18 @@ class NativeShardExchange:
             # diagnostic (bench.py --emulate-ranks with TR_EMULATE_LOOPBACK=1): ONE process plays rank `rank` of `world`; a
             # collective copies this rank's contribution into every slot on the device, so the unpack sees `world` shards
             # (the volume of a real run, not its contents).
-            # (world device-to-device copies through the HIP runtime itself, no torch objects on the frame's host thread; the
-            # emulated frame is GPU-bound either way: host 0.16 ms per frame against 0.22)
-            hip = C.CDLL("libamdhip64.so")
-            hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
-            hip.hipMemcpyAsync.restype = C.c_int
-
+            # (ONE broadcasting copy kernel through torch: world hipMemcpyAsync calls were measured -- eight 5-us copy launches in a
+            # row on the exchange stream, the same frame: 0.218 ms either way, the emulated frame is GPU-bound, host 0.16 ms)
             def fn(_user, send, recv, count, stream):
-                nbytes = int(count) * 4
-                for r in range(self.world):
-                    if hip.hipMemcpyAsync(int(recv) + r * nbytes, int(send), nbytes, 3, stream):     # 3 = hipMemcpyDeviceToDevice
-                        import sys
-                        print("loopback all-gather: hipMemcpyAsync failed", file=sys.stderr, flush=True)
-                        return 1
-                return 0
+                try:
+                    with torch.cuda.stream(torch.cuda.ExternalStream(int(stream or 0))):
+                        src = torch.as_tensor(_DevWords(int(send), int(count)), device="cuda")
+                        torch.as_tensor(_DevWords(int(recv), int(count) * self.world), device="cuda").view(self.world, int(count)).copy_(src.unsqueeze(0).expand(self.world, -1))
+                    return 0
+                except Exception as e:          # a ctypes callback cannot propagate
+                    import sys
+                    print(f"loopback all-gather failed: {e}", file=sys.stderr, flush=True)
+                    return 1
             cb = host.ALLGATHER_FN(fn)
             self._keep.append(cb)
             d.slots_allgather = d.late_allgather = C.cast(cb, C.c_void_p).value
