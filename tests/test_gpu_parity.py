@@ -630,6 +630,21 @@ def test_three_kernel_instance_pass_on_small_scenes():
     assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
 
 
+@pytest.mark.parametrize("percent", ["0", "37", "100"])
+def test_footprint_table_strips_split_between_scan_and_emit(percent):
+    """A large early instance pass builds the HZB's footprint table with extra workgroups of its scan and emit launches (half of
+    the strips each); TRHIP_QUAD_SCAN_PERCENT moves the split.  The table-kernel cases on small and non-square HZBs through the
+    three-kernel instance pass with all strips in emit, an odd split, all in scan."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TRHIP_NO_FUSED_INSTANCE="1", TRHIP_QUAD_SCAN_PERCENT=percent)
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "table_kernel_on_small"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0 and "4 passed" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
 def test_texel_kernel_batch_path_on_small_passes():
     """A pass with at most two records per half-wave of the texel kernel's grid (every late pass, most small early passes of this
     file: 65 535 records of capacity = 4096 half-waves) skips the kernel's batch machinery: every half-wave evaluates its records
